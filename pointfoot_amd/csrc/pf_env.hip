@@ -1,0 +1,152 @@
+// pf_env.hip — launch side of the fused env-step kernel + the pf_* half of the C ABI.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/pointfoot_hip.h"
+#include "pf_layout.h"
+#include "pf_step_kernel.h"
+
+thread_local std::string g_pf_error;
+void pf_set_error(const std::string& s) { g_pf_error = s; }
+
+#define PF_HIP_OK(expr)                                                                    \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      pf_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+      return 1;                                                                            \
+    }                                                                                      \
+  } while (0)
+
+// One wavefront (= one 64-thread workgroup) per robot.  LDS per workgroup is sizeof(Shared); the
+// grid is num_envs workgroups, dealt round-robin over the 8 XCDs by the dispatcher; every env only
+// touches its own record, so no inter-workgroup ordering is needed.
+template <int NB, int ND, int NF>
+__global__ __launch_bounds__(64) void pf_step_kernel(PfStepArgs g) {
+  using K = PfKernel<NB, ND, NF>;
+  __shared__ typename K::Shared sh;
+  K::run(sh, g, (int)blockIdx.x);
+}
+
+struct PfEnv {
+  PfModel model;
+  PfConfig cfg;
+  PfLayout layout;
+  PfBuffers bufs;
+  PfModel* d_model = nullptr;
+  PfConfig* d_cfg = nullptr;
+  int device = 0;
+  bool bound = false;
+};
+
+extern "C" {
+
+const char* pf_last_error(void) { return g_pf_error.c_str(); }
+
+int pf_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out) {
+  if (!model || !cfg || !out) { pf_set_error("pf_layout: null argument"); return 1; }
+  pf_compute_layout(model, cfg, out);
+  if (out->rec_floats > PF_REC_MAX) { pf_set_error("pf_layout: state record exceeds PF_REC_MAX"); return 1; }
+  return 0;
+}
+
+static int pf_validate(const PfModel* m, const PfConfig* c) {
+  if (!(m->nb == 9 && m->nd == 6 && m->nfeet == 2)) {
+    pf_set_error("pf_create: no kernel instance for this model (built: 9 bodies / 6 dofs / 2 feet)");
+    return 1;
+  }
+  if (m->nsph > PF_MAX_SPHERES || c->num_obs > PF_MAX_OBS || c->num_height_points > PF_MAX_HPTS ||
+      c->num_rewards >= PF_MAX_REWARDS || c->num_actions != m->nd || c->num_obs != 9 + 3 * m->nd) {
+    pf_set_error("pf_create: configuration outside the compiled limits");
+    return 1;
+  }
+  for (int i = 1; i < m->nb; ++i)
+    if (m->parent[i] < 0 || m->parent[i] >= i) { pf_set_error("pf_create: bodies must be in depth-first order"); return 1; }
+  return 0;
+}
+
+PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device) {
+  if (!model || !cfg) { pf_set_error("pf_create: null argument"); return nullptr; }
+  if (pf_validate(model, cfg)) return nullptr;
+  PfEnv* e = new PfEnv();
+  e->model = *model; e->cfg = *cfg; e->device = device;
+  pf_compute_layout(model, cfg, &e->layout);
+  if (e->layout.rec_floats > PF_REC_MAX) { pf_set_error("pf_create: state record exceeds PF_REC_MAX"); delete e; return nullptr; }
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&e->d_model, sizeof(PfModel)) != hipSuccess ||
+      hipMalloc(&e->d_cfg, sizeof(PfConfig)) != hipSuccess ||
+      hipMemcpy(e->d_model, model, sizeof(PfModel), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(e->d_cfg, cfg, sizeof(PfConfig), hipMemcpyHostToDevice) != hipSuccess) {
+    pf_set_error("pf_create: HIP device allocation failed (is a GPU visible?)");
+    delete e;
+    return nullptr;
+  }
+  return e;
+}
+
+void pf_destroy(PfEnv* e) {
+  if (!e) return;
+  if (e->d_model) (void)hipFree(e->d_model);
+  if (e->d_cfg) (void)hipFree(e->d_cfg);
+  delete e;
+}
+
+int pf_bind_buffers(PfEnv* e, const PfBuffers* b) {
+  if (!e || !b) { pf_set_error("pf_bind_buffers: null argument"); return 1; }
+  if (!b->d_state || !b->d_episode_length || !b->d_reset || !b->d_time_out || !b->d_terminate || !b->d_obs || !b->d_rew) {
+    pf_set_error("pf_bind_buffers: a required buffer is NULL");
+    return 1;
+  }
+  if (e->cfg.num_priv_obs > 0 && !b->d_priv) { pf_set_error("pf_bind_buffers: d_priv required"); return 1; }
+  if (e->cfg.terrain_type == PF_TERRAIN_HEIGHTFIELD && (!b->d_height_samples || e->cfg.hf_rows < 2 || e->cfg.hf_cols < 2)) {
+    pf_set_error("pf_bind_buffers: height field required for this terrain type"); return 1;
+  }
+  if (e->cfg.curriculum && (!b->d_terrain_level || !b->d_terrain_type || !b->d_terrain_origins)) {
+    pf_set_error("pf_bind_buffers: terrain curriculum buffers required"); return 1;
+  }
+  e->bufs = *b; e->bound = true;
+  return 0;
+}
+
+int pf_update_config(PfEnv* e, const PfConfig* cfg) {
+  if (!e || !cfg) { pf_set_error("pf_update_config: null argument"); return 1; }
+  if (pf_validate(&e->model, cfg)) return 1;
+  if (cfg->num_envs != e->cfg.num_envs || cfg->num_rewards != e->cfg.num_rewards || cfg->num_obs != e->cfg.num_obs ||
+      cfg->num_height_points != e->cfg.num_height_points) {
+    pf_set_error("pf_update_config: shape-changing fields cannot be updated"); return 1;
+  }
+  e->cfg = *cfg;
+  PF_HIP_OK(hipMemcpy(e->d_cfg, cfg, sizeof(PfConfig), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, const PfInject* inject, void* stream, int mode) {
+  if (!e || !e->bound) { pf_set_error("pf_step: buffers not bound"); return 1; }
+  if (mode == 0 && !d_actions) { pf_set_error("pf_step: actions pointer is NULL"); return 1; }
+  PfStepArgs g;
+  g.model = e->d_model; g.cfg = e->d_cfg; g.L = e->layout; g.b = e->bufs;
+  if (inject) g.inj = *inject; else std::memset(&g.inj, 0, sizeof(g.inj));
+  if (g.inj.d_root && !(g.inj.d_dof_pre && g.inj.d_dof_post && g.inj.d_contact && g.inj.d_feet_pos)) {
+    pf_set_error("pf_step: incomplete injected sim state"); return 1;
+  }
+  g.actions = d_actions; g.step_counter = step_counter; g.mode = mode;
+  hipStream_t s = (hipStream_t)stream;
+  if (e->bufs.d_reset_stats && mode != 2) PF_HIP_OK(hipMemsetAsync(e->bufs.d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS, s));
+  hipLaunchKernelGGL((pf_step_kernel<9, 6, 2>), dim3(e->cfg.num_envs), dim3(64), 0, s, g);
+  PF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int pf_step(PfEnv* e, const float* d_actions, int64_t step_counter, const PfInject* inject, void* stream) {
+  return pf_launch(e, d_actions, step_counter, inject, stream, 0);
+}
+int pf_reset_all(PfEnv* e, int64_t step_counter, const PfInject* inject, void* stream) {
+  return pf_launch(e, nullptr, step_counter, inject, stream, 1);
+}
+int pf_compute_observations(PfEnv* e, int64_t step_counter, const PfInject* inject, void* stream) {
+  return pf_launch(e, nullptr, step_counter, inject, stream, 2);
+}
+
+}  // extern "C"

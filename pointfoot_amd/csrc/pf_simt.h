@@ -1,0 +1,41 @@
+// pf_simt.h — the small SIMT vocabulary the env-step kernel is written in.
+//
+// One wavefront (64 lanes) owns one robot.  The kernel is a *phase program*: lane-strided loops
+// (PF_LANES) that touch only their own items, separated by PF_SYNC(), plus "uniform" sections that
+// every lane executes redundantly (all branches on env state are wave-uniform because a wave holds
+// exactly one env).  Shared data lives in LDS.
+//
+// With -DPF_HOST_EMU (used ONLY by tests/, never by the product library) the same program compiles
+// as plain serial C++: PF_LANES becomes an ordinary loop and barriers vanish.  That build checks
+// the kernel's arithmetic and indexing on a machine without a GPU; it cannot detect missing barriers.
+#pragma once
+
+#if defined(PF_HOST_EMU)
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#define PF_DEV static inline
+#define PF_LANES(i, n) for (int i = 0; i < (n); ++i)
+#define PF_SYNC() ((void)0)
+#define PF_ONE if (true)
+#define PF_WAVE_SUM(x) (x)
+#define PF_WAVE_MAX(x) (x)
+#define PF_ATOMIC_ADD(p, v) (*(p) += (v))
+#define PF_NOCONTRACT
+#define PF_LANE_ID 0
+#else
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#define PF_DEV static __device__ __forceinline__
+#define PF_LANES(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
+#define PF_SYNC() __syncthreads()
+#define PF_ONE if (threadIdx.x == 0)
+PF_DEV float pf_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#define PF_WAVE_SUM(x) pf_wave_sum(x)
+#define PF_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define PF_LANE_ID ((int)threadIdx.x)
+#endif

@@ -1,0 +1,888 @@
+// pf_step_kernel.h — the fused env-step program: PD torques, `decimation` articulated-body substeps,
+// and the whole post_physics_step (base-frame quantities, height scan, feet state machine, heading /
+// push callback, termination, reward stack, masked reset with curriculum, observations + noise).
+//
+// Replaces PointFoot.step / post_physics_step (reference legged_gym/envs/pointfoot/point_foot.py:170-230)
+// and the Isaac Gym simulate call inside it (:183).  One wavefront per robot; the env's state record,
+// the body frames, the 12x12 mass matrix and the constraint rows live in LDS (struct Shared).
+// Written in the phase vocabulary of pf_simt.h.  Line references (:NNN) are to point_foot.py.
+#pragma once
+#include "../../include/pointfoot_hip.h"
+#include "pf_simt.h"
+
+#define PF_REC_MAX 256
+#define PF_MAXC 8
+
+// ------------------------------------------------------------------------------------ small math
+PF_DEV float pf_clip(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+PF_DEV void pf_cross(const float* a, const float* b, float* o) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+PF_DEV float pf_dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+PF_DEV void pf_mat_vec(const float* A, const float* v, float* o) {
+  float x = A[0] * v[0] + A[1] * v[1] + A[2] * v[2];
+  float y = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
+  float z = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+PF_DEV void pf_mat_mul(const float* A, const float* B, float* C) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) C[i] = t[i];
+}
+// sym 3x3 stored xx,yy,zz,xy,xz,yz
+PF_DEV void pf_sym_vec(const float* I, const float* v, float* o) {
+  float x = I[0] * v[0] + I[3] * v[1] + I[4] * v[2];
+  float y = I[3] * v[0] + I[1] * v[1] + I[5] * v[2];
+  float z = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+// spatial inertia about O: I10 = {m, hx,hy,hz, Ixx,Iyy,Izz,Ixy,Ixz,Iyz}; v6/o6 = {ang(3), lin(3)}
+PF_DEV void pf_spI_mul(const float* I10, const float* v6, float* o6) {
+  float a[3], hxl[3], hxa[3];
+  pf_sym_vec(I10 + 4, v6, a);
+  pf_cross(I10 + 1, v6 + 3, hxl);
+  pf_cross(I10 + 1, v6, hxa);
+  o6[0] = a[0] + hxl[0]; o6[1] = a[1] + hxl[1]; o6[2] = a[2] + hxl[2];
+  o6[3] = I10[0] * v6[3] - hxa[0]; o6[4] = I10[0] * v6[4] - hxa[1]; o6[5] = I10[0] * v6[5] - hxa[2];
+}
+// isaacgym.torch_utils.quat_rotate (+1) / quat_rotate_inverse (-1), torch op order
+PF_DEV void pf_quat_rotate_dir(const float* q, const float* v, float sign, float* out) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+  float w = q[3];
+  float s = 2.0f * (w * w) - 1.0f;
+  float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+  float d = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+  float o0 = (v[0] * s + sign * (cx * w * 2.0f)) + q[0] * d * 2.0f;
+  float o1 = (v[1] * s + sign * (cy * w * 2.0f)) + q[1] * d * 2.0f;
+  float o2 = (v[2] * s + sign * (cz * w * 2.0f)) + q[2] * d * 2.0f;
+  out[0] = o0; out[1] = o1; out[2] = o2;
+}
+PF_DEV void pf_quat_apply(const float* a, const float* b, float* out) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+  float tx = (a[1] * b[2] - a[2] * b[1]) * 2.0f, ty = (a[2] * b[0] - a[0] * b[2]) * 2.0f, tz = (a[0] * b[1] - a[1] * b[0]) * 2.0f;
+  float ux = a[1] * tz - a[2] * ty, uy = a[2] * tx - a[0] * tz, uz = a[0] * ty - a[1] * tx;
+  out[0] = (b[0] + a[3] * tx) + ux; out[1] = (b[1] + a[3] * ty) + uy; out[2] = (b[2] + a[3] * tz) + uz;
+}
+// legged_gym/utils/math.py:45-48 with torch.remainder semantics
+PF_DEV float pf_wrap_to_pi(float a) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+  const float two_pi = 6.28318530717958647692f, pi = 3.14159265358979323846f;
+  float mod = fmodf(a, two_pi);
+  if (mod != 0.0f && mod < 0.0f) mod += two_pi;
+  if (mod > pi) mod -= two_pi;
+  return mod;
+}
+
+// Philox4x32-10 (Salmon et al. 2011); counter = (global env, step, stream, slot/4), key = seed
+PF_DEV float pf_philox_slot(uint32_t k0, uint32_t k1, uint32_t env, uint32_t step, uint32_t stream, uint32_t slot) {
+  uint32_t c0 = env, c1 = step, c2 = stream, c3 = slot >> 2;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  uint32_t s = slot & 3u;
+  uint32_t x = s == 0 ? c0 : (s == 1 ? c1 : (s == 2 ? c2 : c3));
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+struct PfStepArgs {
+  const PfModel* model;   // device copy
+  const PfConfig* cfg;    // device copy
+  PfLayout L;
+  PfBuffers b;
+  PfInject inj;
+  const float* actions;
+  long long step_counter;
+  int mode;               // 0 = step, 1 = reset_idx(all), 2 = compute_observations only
+};
+
+template <int NB, int ND, int NF>
+struct PfKernel {
+  static constexpr int NV = 6 + ND;
+  static constexpr int NVP = NV | 1;          // odd row stride: per-lane rows hit distinct LDS banks
+  static constexpr int MAXC = PF_MAXC;
+  static constexpr int CROWS = 3 * MAXC;
+  static constexpr int RFREE = CROWS + ND;    // extra right-hand side: free acceleration
+  static constexpr int NROWS = RFREE + 1;
+
+  struct Shared {
+    float rec[PF_REC_MAX];
+    float Rw[NB][9], r[NB][3], ax[NB][3];
+    float Sj[NB][6], V[NB][6], A[NB][6];      // {ang, lin@O}
+    float I[NB][10], Ic[NB][10];
+    float f[NB][6], fc[NB][6];                // {moment@O, force}
+    float F[ND][6];
+    float M[NV][NVP];
+    float dinv[NV];
+    float bias[NV], vel[NV], vold[NV];
+    float J[NROWS][NVP], W[NROWS][NVP];
+    float rb[NROWS], rAinv[NROWS], lam[NROWS];
+    float cA[MAXC][9], cdir[MAXC][9];
+    int cbody[MAXC], con_sph[MAXC], lim_dof[ND], lim_side[ND];
+    float sphx[PF_MAX_SPHERES][3], sphn[PF_MAX_SPHERES][3], sphd[PF_MAX_SPHERES];
+    int sphact[PF_MAX_SPHERES];
+    float heights[PF_MAX_HPTS];
+  };
+
+  // ------------------------------------------------------------------ terrain
+  // point_foot.py:1100-1112 for one point; exact float32 op order of the reference, no FMA contraction
+  PF_DEV float height_raw(const PfConfig& c, const int16_t* hs, float wx, float wy) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+    float fx = (wx + c.border) / c.hscale;
+    float fy = (wy + c.border) / c.hscale;
+    int ix = (int)fx, iy = (int)fy;
+    ix = ix < 0 ? 0 : (ix > c.hf_rows - 2 ? c.hf_rows - 2 : ix);
+    iy = iy < 0 ? 0 : (iy > c.hf_cols - 2 ? c.hf_cols - 2 : iy);
+    int h1 = hs[ix * c.hf_cols + iy], h2 = hs[(ix + 1) * c.hf_cols + iy], h3 = hs[ix * c.hf_cols + iy + 1];
+    int h = h1 < h2 ? h1 : h2;
+    h = h < h3 ? h : h3;
+    return (float)h;
+  }
+  // collision surface: bilinear height + normal (own contact model)
+  PF_DEV void terrain_query(const PfConfig& c, const int16_t* hs, float wx, float wy, float* h, float* n) {
+    if (c.terrain_type == PF_TERRAIN_PLANE || hs == nullptr) { *h = 0.0f; n[0] = 0.0f; n[1] = 0.0f; n[2] = 1.0f; return; }
+    float fx = (wx + c.border) / c.hscale, fy = (wy + c.border) / c.hscale;
+    fx = fminf(fmaxf(fx, 0.0f), (float)(c.hf_rows - 1) - 1e-3f);
+    fy = fminf(fmaxf(fy, 0.0f), (float)(c.hf_cols - 1) - 1e-3f);
+    int ix = (int)fx, iy = (int)fy;
+    float tx = fx - (float)ix, ty = fy - (float)iy;
+    float h00 = hs[ix * c.hf_cols + iy], h10 = hs[(ix + 1) * c.hf_cols + iy], h01 = hs[ix * c.hf_cols + iy + 1], h11 = hs[(ix + 1) * c.hf_cols + iy + 1];
+    *h = c.vscale * ((1.0f - tx) * ((1.0f - ty) * h00 + ty * h01) + tx * ((1.0f - ty) * h10 + ty * h11));
+    float dhdx = c.vscale * ((1.0f - ty) * (h10 - h00) + ty * (h11 - h01)) / c.hscale;
+    float dhdy = c.vscale * ((1.0f - tx) * (h01 - h00) + tx * (h11 - h10)) / c.hscale;
+    float inv = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
+    n[0] = -dhdx * inv; n[1] = -dhdy * inv; n[2] = inv;
+  }
+
+  PF_DEV float rnd(const PfConfig& c, const PfLayout& L, const PfInject& inj, int env, long long step, int slot) {
+    if (inj.d_rand) return inj.d_rand[(size_t)env * L.rand_floats + slot];
+    return pf_philox_slot(c.seed_lo, c.seed_hi, (uint32_t)(c.env_index_base + env), (uint32_t)step, 0u, (uint32_t)slot);
+  }
+
+  // ------------------------------------------------------------------ PD torques (:523-547)
+  PF_DEV void torques(Shared& sh, const PfConfig& c, const PfLayout& L, const float* qsrc, int qstride, int voff) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+    PF_LANES(k, ND) {
+      float qp = qsrc[k * qstride], qv = qsrc[k * qstride + voff];
+      float as = sh.rec[L.actions + k] * c.action_scale, t;
+      if (c.control_type == PF_CTRL_P) t = c.p_gains[k] * ((as + c.default_dof_pos[k]) - qp) - c.d_gains[k] * qv;
+      else if (c.control_type == PF_CTRL_V) t = c.p_gains[k] * (as - qv) - c.d_gains[k] * (qv - sh.rec[L.last_dof_vel + k]) / c.sim_dt;
+      else t = as;
+      sh.rec[L.torques + k] = pf_clip(t, -c.torque_limits[k], c.torque_limits[k]);
+    }
+    PF_SYNC();
+  }
+
+  // ------------------------------------------------------------------ forward kinematics (+ velocities)
+  template <bool WITH_VEL>
+  PF_DEV void kinematics(Shared& sh, const PfModel& m, const PfConfig& c, const PfLayout& L) {
+    const float* S = sh.rec;
+    int maxdepth = 0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) maxdepth = m.depth[i] > maxdepth ? m.depth[i] : maxdepth;
+    PF_LANES(i, 1) {
+      const float* q = S + L.root + 3;
+      float x = q[0], y = q[1], z = q[2], w = q[3];
+      float* R = sh.Rw[0];
+      R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+      R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+      R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+      sh.r[0][0] = 0.0f; sh.r[0][1] = 0.0f; sh.r[0][2] = 0.0f;
+      if (WITH_VEL) {
+        const float* vb = S + L.root + 7; const float* wb = S + L.root + 10;
+        float wxv[3]; pf_cross(wb, vb, wxv);
+        for (int t = 0; t < 3; ++t) {
+          sh.V[0][t] = wb[t]; sh.V[0][3 + t] = vb[t];
+          sh.A[0][t] = 0.0f; sh.A[0][3 + t] = -wxv[t] - c.gravity[t];
+          sh.Sj[0][t] = 0.0f; sh.Sj[0][3 + t] = 0.0f;
+        }
+      }
+    }
+    PF_SYNC();
+    for (int lvl = 1; lvl <= maxdepth; ++lvl) {
+      PF_LANES(i, NB) {
+        if (m.depth[i] != lvl) continue;
+        int p = m.parent[i];
+        float Rj[9]; pf_mat_mul(sh.Rw[p], m.joint_rot[i], Rj);
+        float rp[3]; pf_mat_vec(sh.Rw[p], m.joint_pos[i], rp);
+        float ri[3] = {sh.r[p][0] + rp[0], sh.r[p][1] + rp[1], sh.r[p][2] + rp[2]};
+        sh.r[i][0] = ri[0]; sh.r[i][1] = ri[1]; sh.r[i][2] = ri[2];
+        int k = m.dof_of_body[i];
+        if (k >= 0) {
+          const float* a = m.joint_axis[i];
+          float aw[3]; pf_mat_vec(Rj, a, aw);
+          float th = S[L.dof_pos + k];
+          float cs = cosf(th), sn = sinf(th), t1 = 1.0f - cs;
+          float Ra[9] = {t1 * a[0] * a[0] + cs, t1 * a[0] * a[1] - sn * a[2], t1 * a[0] * a[2] + sn * a[1],
+                         t1 * a[0] * a[1] + sn * a[2], t1 * a[1] * a[1] + cs, t1 * a[1] * a[2] - sn * a[0],
+                         t1 * a[0] * a[2] - sn * a[1], t1 * a[1] * a[2] + sn * a[0], t1 * a[2] * a[2] + cs};
+          pf_mat_mul(Rj, Ra, sh.Rw[i]);
+          sh.ax[i][0] = aw[0]; sh.ax[i][1] = aw[1]; sh.ax[i][2] = aw[2];
+          if (WITH_VEL) {
+            float sl[3]; pf_cross(ri, aw, sl);
+            float qd = S[L.dof_vel + k];
+            float Vi[6];
+            for (int t = 0; t < 3; ++t) { sh.Sj[i][t] = aw[t]; sh.Sj[i][3 + t] = sl[t]; Vi[t] = sh.V[p][t] + qd * aw[t]; Vi[3 + t] = sh.V[p][3 + t] + qd * sl[t]; }
+            float ca[3], c1[3], c2[3];
+            pf_cross(Vi, aw, ca); pf_cross(Vi, sl, c1); pf_cross(Vi + 3, aw, c2);
+            for (int t = 0; t < 3; ++t) {
+              sh.V[i][t] = Vi[t]; sh.V[i][3 + t] = Vi[3 + t];
+              sh.A[i][t] = sh.A[p][t] + qd * ca[t];
+              sh.A[i][3 + t] = sh.A[p][3 + t] + qd * (c1[t] + c2[t]);
+            }
+          }
+        } else {
+          for (int t = 0; t < 9; ++t) sh.Rw[i][t] = Rj[t];
+          sh.ax[i][0] = 0.0f; sh.ax[i][1] = 0.0f; sh.ax[i][2] = 0.0f;
+          if (WITH_VEL)
+            for (int t = 0; t < 6; ++t) { sh.Sj[i][t] = 0.0f; sh.V[i][t] = sh.V[p][t]; sh.A[i][t] = sh.A[p][t]; }
+        }
+      }
+      PF_SYNC();
+    }
+  }
+
+  // ------------------------------------------------------------------ one physics substep of sim_dt
+  PF_DEV void substep(Shared& sh, const PfModel& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, bool apply_ext) {
+    float* S = sh.rec;
+    const float dt = c.sim_dt;
+    kinematics<true>(sh, m, c, L);
+    // ---- per-body spatial inertia about O and bias wrench
+    PF_LANES(i, NB) {
+      float mass = m.mass[i];
+      float cl[3] = {m.com[i][0], m.com[i][1], m.com[i][2]};
+      float Il[6];
+      for (int t = 0; t < 6; ++t) Il[t] = m.inertia[i][t];
+      if (i == 0) {   // base mass / COM randomisation (:466-477), inertia scaled with mass
+        float added = S[L.added_mass];
+        float sc = (mass + added) / mass;
+        mass += added;
+        for (int t = 0; t < 3; ++t) cl[t] += S[L.added_com + t];
+        for (int t = 0; t < 6; ++t) Il[t] *= sc;
+      }
+      const float* R = sh.Rw[i];
+      float cw[3]; pf_mat_vec(R, cl, cw);
+      for (int t = 0; t < 3; ++t) cw[t] += sh.r[i][t];
+      float Ilm[9] = {Il[0], Il[3], Il[4], Il[3], Il[1], Il[5], Il[4], Il[5], Il[2]};
+      float T[9]; pf_mat_mul(R, Ilm, T);
+      float Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+      float Iw[9]; pf_mat_mul(T, Rt, Iw);
+      float c2 = pf_dot3(cw, cw);
+      float I10[10];
+      I10[0] = mass; I10[1] = mass * cw[0]; I10[2] = mass * cw[1]; I10[3] = mass * cw[2];
+      I10[4] = Iw[0] + mass * (c2 - cw[0] * cw[0]);
+      I10[5] = Iw[4] + mass * (c2 - cw[1] * cw[1]);
+      I10[6] = Iw[8] + mass * (c2 - cw[2] * cw[2]);
+      I10[7] = Iw[1] - mass * cw[0] * cw[1];
+      I10[8] = Iw[2] - mass * cw[0] * cw[2];
+      I10[9] = Iw[5] - mass * cw[1] * cw[2];
+      for (int t = 0; t < 10; ++t) sh.I[i][t] = I10[t];
+      float Vi[6], Ai[6], IA[6], IV[6];
+      for (int t = 0; t < 6; ++t) { Vi[t] = sh.V[i][t]; Ai[t] = sh.A[i][t]; }
+      pf_spI_mul(I10, Ai, IA); pf_spI_mul(I10, Vi, IV);
+      float x1[3], x2[3], x3[3];
+      pf_cross(Vi, IV, x1); pf_cross(Vi + 3, IV + 3, x2); pf_cross(Vi, IV + 3, x3);
+      for (int t = 0; t < 3; ++t) { sh.f[i][t] = IA[t] + x1[t] + x2[t]; sh.f[i][3 + t] = IA[3 + t] + x3[t]; }
+      if (i == 0 && apply_ext)
+        for (int t = 0; t < 3; ++t) sh.f[0][3 + t] -= S[L.ext_force + t];
+    }
+    PF_SYNC();
+    // ---- composites over DFS-contiguous subtrees
+    PF_LANES(i, NB) {
+      float Ic[10], fc[6];
+      for (int t = 0; t < 10; ++t) Ic[t] = sh.I[i][t];
+      for (int t = 0; t < 6; ++t) fc[t] = sh.f[i][t];
+      int end = i + m.subtree[i];
+      for (int j = i + 1; j < end; ++j) {
+        for (int t = 0; t < 10; ++t) Ic[t] += sh.I[j][t];
+        for (int t = 0; t < 6; ++t) fc[t] += sh.f[j][t];
+      }
+      for (int t = 0; t < 10; ++t) sh.Ic[i][t] = Ic[t];
+      for (int t = 0; t < 6; ++t) sh.fc[i][t] = fc[t];
+    }
+    PF_SYNC();
+    PF_LANES(k, ND) {
+      int i = m.body_of_dof[k];
+      float Ic[10], Sv[6], Fo[6];
+      for (int t = 0; t < 10; ++t) Ic[t] = sh.Ic[i][t];
+      for (int t = 0; t < 6; ++t) Sv[t] = sh.Sj[i][t];
+      pf_spI_mul(Ic, Sv, Fo);
+      for (int t = 0; t < 6; ++t) sh.F[k][t] = Fo[t];
+    }
+    PF_SYNC();
+    // ---- mass matrix (lower triangle; generalised velocity [v_O, w, qd]) + bias + old velocity
+    PF_LANES(e, NV * NV) {
+      int a = e / NV, b = e - a * NV;
+      if (b > a) continue;
+      float v = 0.0f;
+      if (a < 6) {
+        const float* C = sh.Ic[0];
+        if (a < 3) v = (a == b) ? C[0] : 0.0f;
+        else if (b >= 3) {
+          int x = a - 3, y = b - 3;
+          v = (x == y) ? C[4 + x] : C[7 + (x + y - 1)];      // (0,1)->xy, (0,2)->xz, (1,2)->yz
+        } else {
+          // M_ang,lin = [h]x : row x = a-3, col y = b
+          int x = a - 3, y = b;
+          if (x == y) v = 0.0f;
+          else if ((x + 1) % 3 == y) v = -C[1 + (3 - x - y)];   // (0,1)->-hz,(1,2)->-hx,(2,0)->-hy
+          else v = C[1 + (3 - x - y)];
+        }
+      } else {
+        int ka = a - 6;
+        if (b < 6) v = b < 3 ? sh.F[ka][3 + b] : sh.F[ka][b - 3];
+        else {
+          int kb = b - 6, ia = m.body_of_dof[ka], ib = m.body_of_dof[kb];
+          if (ib <= ia && ia < ib + m.subtree[ib]) v = pf_dot3(sh.Sj[ib], sh.F[ka]) + pf_dot3(sh.Sj[ib] + 3, sh.F[ka] + 3);
+          else if (ia <= ib && ib < ia + m.subtree[ia]) v = pf_dot3(sh.Sj[ia], sh.F[kb]) + pf_dot3(sh.Sj[ia] + 3, sh.F[kb] + 3);
+        }
+      }
+      sh.M[a][b] = v;
+    }
+    PF_LANES(a, NV) {
+      float bv, vo;
+      if (a < 3) { bv = sh.fc[0][3 + a]; vo = S[L.root + 7 + a]; }
+      else if (a < 6) { bv = sh.fc[0][a - 3]; vo = S[L.root + 7 + a]; }
+      else {
+        int k = a - 6, i = m.body_of_dof[k];
+        bv = pf_dot3(sh.Sj[i], sh.fc[i]) + pf_dot3(sh.Sj[i] + 3, sh.fc[i] + 3);
+        vo = S[L.dof_vel + k];
+      }
+      sh.bias[a] = bv; sh.vold[a] = vo;
+      float rhs = -bv + (a >= 6 ? S[L.torques + a - 6] : 0.0f);
+      sh.J[RFREE][a] = rhs; sh.W[RFREE][a] = rhs;
+    }
+    PF_SYNC();
+    // ---- in-place Cholesky, one column per phase
+    for (int j = 0; j < NV; ++j) {
+      float d = sh.M[j][j];
+      for (int t = 0; t < j; ++t) d -= sh.M[j][t] * sh.M[j][t];
+      d = sqrtf(fmaxf(d, 1e-12f));
+      float di = 1.0f / d;
+      PF_LANES(ii, NV - j - 1) {
+        int i = j + 1 + ii;
+        float s = sh.M[i][j];
+        for (int t = 0; t < j; ++t) s -= sh.M[i][t] * sh.M[j][t];
+        sh.M[i][j] = s * di;
+      }
+      PF_ONE { sh.dinv[j] = di; }
+      PF_SYNC();
+    }
+    // ---- contact candidates: every collision sphere against the terrain
+    const int16_t* hs = B.d_height_samples;
+    PF_LANES(s, m.nsph) {
+      int i = m.sph_body[s];
+      float xs[3]; pf_mat_vec(sh.Rw[i], m.sph_pos[s], xs);
+      for (int t = 0; t < 3; ++t) xs[t] += sh.r[i][t];
+      float h, n[3];
+      terrain_query(c, hs, S[L.root] + xs[0], S[L.root + 1] + xs[1], &h, n);
+      float rad = m.sph_radius[s];
+      float dist = (S[L.root + 2] + xs[2] - h) * n[2] - rad;
+      sh.sphact[s] = dist < c.contact_offset ? 1 : 0;
+      sh.sphd[s] = dist;
+      for (int t = 0; t < 3; ++t) { sh.sphx[s][t] = xs[t] - rad * n[t]; sh.sphn[s][t] = n[t]; }
+    }
+    PF_SYNC();
+    int ncon = 0;
+    for (int s = 0; s < m.nsph; ++s) ncon += sh.sphact[s];
+    ncon = ncon < MAXC ? ncon : MAXC;
+    PF_LANES(s, m.nsph) {
+      if (!sh.sphact[s]) continue;
+      int idx = 0;
+      for (int t = 0; t < s; ++t) idx += sh.sphact[t];
+      if (idx < MAXC) { sh.con_sph[idx] = s; sh.cbody[idx] = m.sph_body[s]; }
+    }
+    PF_SYNC();
+    // ---- contact rows: Jacobians, targets, then W = M^-1 J^T (one lane per row; + the free-acceleration row)
+    const float rest = 0.5f * c.terrain_restitution;
+    PF_LANES(rr, 3 * ncon) {
+      int ci = rr / 3, d = rr - 3 * ci;
+      int s = sh.con_sph[ci], i = m.sph_body[s];
+      float n[3] = {sh.sphn[s][0], sh.sphn[s][1], sh.sphn[s][2]};
+      float ref[3] = {fabsf(n[0]) < 0.9f ? 1.0f : 0.0f, fabsf(n[0]) < 0.9f ? 0.0f : 1.0f, 0.0f};
+      float t1[3]; pf_cross(n, ref, t1);
+      float il = 1.0f / sqrtf(pf_dot3(t1, t1));
+      for (int t = 0; t < 3; ++t) t1[t] *= il;
+      float t2[3]; pf_cross(n, t1, t2);
+      float dd[3];
+      for (int t = 0; t < 3; ++t) dd[t] = d == 0 ? n[t] : (d == 1 ? t1[t] : t2[t]);
+      for (int t = 0; t < 3; ++t) sh.cdir[ci][3 * d + t] = dd[t];
+      float xc[3] = {sh.sphx[s][0], sh.sphx[s][1], sh.sphx[s][2]};
+      float row[NV];
+#pragma unroll
+      for (int a = 0; a < NV; ++a) row[a] = 0.0f;
+      row[0] = dd[0]; row[1] = dd[1]; row[2] = dd[2];
+      float xa[3]; pf_cross(xc, dd, xa);
+      row[3] = xa[0]; row[4] = xa[1]; row[5] = xa[2];
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        int j = m.body_of_dof[k];
+        if (j <= i && i < j + m.subtree[j]) {
+          float rel[3] = {xc[0] - sh.r[j][0], xc[1] - sh.r[j][1], xc[2] - sh.r[j][2]};
+          float cr[3]; pf_cross(rel, dd, cr);
+          row[6 + k] = pf_dot3(sh.ax[j], cr);
+        }
+      }
+      float un0 = 0.0f;
+#pragma unroll
+      for (int a = 0; a < NV; ++a) { sh.J[rr][a] = row[a]; sh.W[rr][a] = row[a]; un0 += row[a] * sh.vold[a]; }
+      float bn = 0.0f;
+      if (d == 0) {
+        float dist = sh.sphd[s];
+        bn = dist >= 0.0f ? -dist / dt : fminf(0.2f * (-dist) / dt, c.max_depenetration_vel);
+        if (un0 < -c.bounce_threshold) bn = fmaxf(bn, -rest * un0);
+      }
+      sh.rb[rr] = bn; sh.lam[rr] = 0.0f;
+    }
+    PF_SYNC();
+    solve_rows(sh, 3 * ncon, true);
+    PF_SYNC();
+    // ---- free velocity
+    PF_LANES(a, NV) sh.vel[a] = sh.vold[a] + dt * sh.W[RFREE][a];
+    PF_SYNC();
+    // ---- joint-limit rows (need the free velocity)
+    PF_LANES(k, ND) {
+      float q = S[L.dof_pos + k], qn = q + dt * sh.vel[6 + k];
+      float lo = m.q_lo[k], hi = m.q_hi[k];
+      int side = 0;
+      if (q < lo || qn < lo) side = 1; else if (q > hi || qn > hi) side = -1;
+      sh.lim_side[k] = side;
+    }
+    PF_SYNC();
+    int nlim = 0;
+    for (int k = 0; k < ND; ++k) nlim += sh.lim_side[k] != 0 ? 1 : 0;
+    PF_LANES(k, ND) {
+      int side = sh.lim_side[k];
+      if (side == 0) continue;
+      int idx = 0;
+      for (int t = 0; t < k; ++t) idx += sh.lim_side[t] != 0 ? 1 : 0;
+      int rr = CROWS + idx;
+      sh.lim_dof[idx] = k;
+      for (int a = 0; a < NV; ++a) { float v = (a == 6 + k) ? (float)side : 0.0f; sh.J[rr][a] = v; sh.W[rr][a] = v; }
+      float q = S[L.dof_pos + k];
+      float viol = side > 0 ? m.q_lo[k] - q : q - m.q_hi[k];
+      sh.rb[rr] = viol > 0.0f ? fminf(0.2f * viol / dt, 10.0f * c.max_depenetration_vel) : viol / dt;
+      sh.lam[rr] = 0.0f;
+    }
+    PF_SYNC();
+    solve_rows_range(sh, CROWS, nlim);
+    PF_SYNC();
+    // ---- per-contact 3x3 Delassus blocks
+    PF_LANES(e, ncon * 9) {
+      int ci = e / 9, ab = e - 9 * ci, a = ab / 3, b = ab - 3 * a;
+      float s = 0.0f;
+      for (int t = 0; t < NV; ++t) s += sh.J[3 * ci + a][t] * sh.W[3 * ci + b][t];
+      sh.cA[ci][ab] = s;
+    }
+    PF_SYNC();
+    // ---- projected Gauss-Seidel (uniform impulse math, lane-parallel velocity update)
+    const float mu = 0.5f * (S[L.friction] + c.terrain_friction);
+    for (int it = 0; it < c.solver_iterations; ++it) {
+      for (int ci = 0; ci < ncon; ++ci) {
+        int r0 = 3 * ci;
+        float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
+        for (int t = 0; t < NV; ++t) { float v = sh.vel[t]; u0 += sh.J[r0][t] * v; u1 += sh.J[r0 + 1][t] * v; u2 += sh.J[r0 + 2][t] * v; }
+        float l0 = sh.lam[r0], l1o = sh.lam[r0 + 1], l2o = sh.lam[r0 + 2];
+        float ln = fmaxf(0.0f, l0 + (sh.rb[r0] - u0) * sh.rAinv[r0]);
+        float d0 = ln - l0;
+        float u1c = u1 + sh.cA[ci][3] * d0;
+        float l1 = l1o - u1c * sh.rAinv[r0 + 1];
+        float d1p = l1 - l1o;
+        float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
+        float l2 = l2o - u2c * sh.rAinv[r0 + 2];
+        float lim = mu * ln, nt = sqrtf(l1 * l1 + l2 * l2);
+        if (nt > lim) { float sc = nt > 0.0f ? lim / nt : 0.0f; l1 *= sc; l2 *= sc; }
+        float d1 = l1 - l1o, d2 = l2 - l2o;
+        PF_SYNC();   // all lanes have read vel / lam before anyone overwrites them
+        PF_LANES(t, NV) sh.vel[t] += sh.W[r0][t] * d0 + sh.W[r0 + 1][t] * d1 + sh.W[r0 + 2][t] * d2;
+        PF_ONE { sh.lam[r0] = ln; sh.lam[r0 + 1] = l1; sh.lam[r0 + 2] = l2; }
+        PF_SYNC();
+      }
+      for (int li = 0; li < nlim; ++li) {
+        int rr = CROWS + li;
+        float u = 0.0f;
+        for (int t = 0; t < NV; ++t) u += sh.J[rr][t] * sh.vel[t];
+        float lo = sh.lam[rr];
+        float ln = fmaxf(0.0f, lo + (sh.rb[rr] - u) * sh.rAinv[rr]);
+        float d = ln - lo;
+        PF_SYNC();
+        PF_LANES(t, NV) sh.vel[t] += sh.W[rr][t] * d;
+        PF_ONE { sh.lam[rr] = ln; }
+        PF_SYNC();
+      }
+    }
+    // ---- integrate (semi-implicit Euler), net contact force per body
+    PF_LANES(k, ND) {
+      float vl = m.vel_limit[k];
+      float v = fminf(fmaxf(sh.vel[6 + k], -vl), vl);
+      S[L.dof_vel + k] = v;
+      S[L.dof_pos + k] += dt * v;
+    }
+    PF_LANES(i, NB) {
+      float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
+      for (int ci = 0; ci < ncon; ++ci) {
+        if (sh.cbody[ci] != i) continue;
+        for (int d = 0; d < 3; ++d) {
+          float l = sh.lam[3 * ci + d] / dt;
+          Fx += l * sh.cdir[ci][3 * d]; Fy += l * sh.cdir[ci][3 * d + 1]; Fz += l * sh.cdir[ci][3 * d + 2];
+        }
+      }
+      S[L.contact_forces + 3 * i] = Fx; S[L.contact_forces + 3 * i + 1] = Fy; S[L.contact_forces + 3 * i + 2] = Fz;
+    }
+    {
+      float w0 = sh.vel[3], w1 = sh.vel[4], w2 = sh.vel[5];
+      float qx = S[L.root + 3], qy = S[L.root + 4], qz = S[L.root + 5], qw = S[L.root + 6];
+      float hx = 0.5f * dt * w0, hy = 0.5f * dt * w1, hz = 0.5f * dt * w2;
+      float nx = qx + (hx * qw + hy * qz - hz * qy);
+      float ny = qy + (-hx * qz + hy * qw + hz * qx);
+      float nz = qz + (hx * qy - hy * qx + hz * qw);
+      float nw = qw + (-hx * qx - hy * qy - hz * qz);
+      float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+      float p0 = S[L.root] + dt * sh.vel[0], p1 = S[L.root + 1] + dt * sh.vel[1], p2 = S[L.root + 2] + dt * sh.vel[2];
+      float v6[6];
+      for (int t = 0; t < 6; ++t) v6[t] = sh.vel[t];
+      PF_SYNC();
+      PF_ONE {
+        S[L.root] = p0; S[L.root + 1] = p1; S[L.root + 2] = p2;
+        S[L.root + 3] = nx * inv; S[L.root + 4] = ny * inv; S[L.root + 5] = nz * inv; S[L.root + 6] = nw * inv;
+        for (int t = 0; t < 6; ++t) S[L.root + 7 + t] = v6[t];
+      }
+    }
+    PF_SYNC();
+  }
+
+  // W[row] <- M^-1 J[row]^T by forward/back substitution on the in-place Cholesky factor; Ainv = 1/(J.W)
+  PF_DEV void solve_one(Shared& sh, int rr) {
+    float* w = sh.W[rr];
+    for (int i = 0; i < NV; ++i) {
+      float s = w[i];
+      for (int t = 0; t < i; ++t) s -= sh.M[i][t] * w[t];
+      w[i] = s * sh.dinv[i];
+    }
+    for (int i = NV - 1; i >= 0; --i) {
+      float s = w[i];
+      for (int t = i + 1; t < NV; ++t) s -= sh.M[t][i] * w[t];
+      w[i] = s * sh.dinv[i];
+    }
+    float a = 0.0f;
+    for (int t = 0; t < NV; ++t) a += sh.J[rr][t] * w[t];
+    sh.rAinv[rr] = 1.0f / fmaxf(a, 1e-9f);
+  }
+  PF_DEV void solve_rows(Shared& sh, int nrows, bool with_free) {
+    PF_LANES(x, nrows + (with_free ? 1 : 0)) { solve_one(sh, x < nrows ? x : RFREE); }
+  }
+  PF_DEV void solve_rows_range(Shared& sh, int first, int n) {
+    PF_LANES(x, n) { solve_one(sh, first + x); }
+  }
+
+  // ------------------------------------------------------------------ observations (:320-382, :189-192)
+  PF_DEV void observations(Shared& sh, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+    const float* S = sh.rec;
+    const int no = c.num_obs, np_ = c.num_priv_obs, na = c.num_actions;
+    PF_LANES(i, no) {
+      float v;
+      if (i < 3) v = S[L.base_ang_vel + i] * c.obs_scale_ang_vel;
+      else if (i < 6) v = S[L.projected_gravity + i - 3];
+      else if (i < 6 + ND) v = (S[L.dof_pos + i - 6] - c.default_dof_pos[i - 6]) * c.obs_scale_dof_pos;
+      else if (i < 6 + 2 * ND) v = S[L.dof_vel + i - 6 - ND] * c.obs_scale_dof_vel;
+      else if (i < 6 + 2 * ND + na) v = S[L.actions + i - 6 - 2 * ND];
+      else { int k = i - 6 - 2 * ND - na; v = S[L.commands + k] * c.commands_scale[k]; }
+      if (c.add_noise) v += (2.0f * rnd(c, L, inj, env, step, L.r_obs + i) - 1.0f) * c.obs_noise_vec[i];
+      v = pf_clip(v, -c.clip_obs, c.clip_obs);
+      B.d_obs[(size_t)env * no + i] = v;
+      if (B.d_priv) B.d_priv[(size_t)env * np_ + i] = v;
+    }
+    if (B.d_priv && c.measure_heights) {
+      PF_LANES(j, c.num_height_points) {    // :367-373
+        float h = pf_clip((S[L.root + 2] - 0.5f) - sh.heights[j], -1.0f, 1.0f) * c.obs_scale_height;
+        if (c.add_noise) h += (2.0f * rnd(c, L, inj, env, step, L.r_priv + j) - 1.0f) * c.priv_height_noise;
+        B.d_priv[(size_t)env * np_ + no + j] = pf_clip(h, -c.clip_obs, c.clip_obs);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ reset_idx for this env (:249-299)
+  PF_DEV void reset_env(Shared& sh, const PfModel& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+    float* S = sh.rec;
+    if (c.curriculum) {     // :613-636
+      float dx = S[L.root] - S[L.env_origin], dy = S[L.root + 1] - S[L.env_origin + 1];
+      float dist = sqrtf(dx * dx + dy * dy);
+      bool up = dist > c.terrain_length / 2.0f;
+      float cn = sqrtf(S[L.commands] * S[L.commands] + S[L.commands + 1] * S[L.commands + 1]);
+      bool down = (dist < cn * c.max_episode_length_s * 0.5f) && !up;
+      int lvl = B.d_terrain_level[env] + (up ? 1 : 0) - (down ? 1 : 0);
+      if (lvl >= c.max_terrain_level) {
+        float u = rnd(c, L, inj, env, step, L.r_level);
+        if (inj.d_rand) lvl = (int)u;
+        else { lvl = (int)(u * (float)c.max_terrain_level); lvl = lvl < c.max_terrain_level - 1 ? lvl : c.max_terrain_level - 1; }
+      } else lvl = lvl > 0 ? lvl : 0;
+      const float* o = B.d_terrain_origins + ((size_t)lvl * c.terrain_num_cols + B.d_terrain_type[env]) * 3;
+      float o0 = o[0], o1 = o[1], o2 = o[2];
+      PF_SYNC();
+      PF_ONE { B.d_terrain_level[env] = lvl; S[L.env_origin] = o0; S[L.env_origin + 1] = o1; S[L.env_origin + 2] = o2; }
+      PF_SYNC();
+    }
+    PF_LANES(k, ND) {       // :549-559
+      S[L.dof_pos + k] = c.default_dof_pos[k] * ((1.5f - 0.5f) * rnd(c, L, inj, env, step, L.r_dof + k) + 0.5f);
+      S[L.dof_vel + k] = 0.0f;
+    }
+    PF_LANES(i, 13) {       // :566-584
+      float v = c.base_init_state[i];
+      if (i < 3) v += S[L.env_origin + i];
+      if (i < 2 && c.custom_origins) v += (1.0f - (-1.0f)) * rnd(c, L, inj, env, step, L.r_xy + i) + (-1.0f);
+      if (i >= 7) v = (0.5f - (-0.5f)) * rnd(c, L, inj, env, step, L.r_vel + i - 7) + (-0.5f);
+      S[L.root + i] = v;
+    }
+    PF_LANES(f, NF) {       // :290-299
+      S[L.feet_air_time + f] = 0.0f; S[L.last_feet_air_time + f] = 0.0f;
+      S[L.cur_max_feet_height + f] = 0.0f; S[L.last_max_feet_height + f] = 0.0f;
+    }
+    int nsum = c.num_rewards + (c.termination_scale != 0.0f ? 1 : 0);
+    PF_LANES(ri, nsum) {    // :276-280
+      if (B.d_reset_stats) PF_ATOMIC_ADD(B.d_reset_stats + ri, S[L.episode_sums + ri]);
+      S[L.episode_sums + ri] = 0.0f;
+    }
+    PF_ONE { if (B.d_reset_stats) PF_ATOMIC_ADD(B.d_reset_stats + PF_MAX_REWARDS, 1.0f); }
+    PF_SYNC();
+  }
+
+  // ------------------------------------------------------------------ the whole step for env `env`
+  PF_DEV void run(Shared& sh, const PfStepArgs& g, int env) {
+    const PfModel& m = *g.model; const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
+    float* S = sh.rec;
+    float* grow = B.d_state + (size_t)env * L.rec_floats;
+    PF_LANES(i, L.rec_floats) S[i] = grow[i];
+    PF_SYNC();
+    if (g.mode == 1) {
+      reset_env(sh, m, c, L, B, inj, env, g.step_counter);
+      PF_ONE { B.d_episode_length[env] = 0; B.d_reset[env] = 1; }
+      PF_LANES(i, L.rec_floats) grow[i] = S[i];
+      return;
+    }
+    if (g.mode == 2) {
+      PF_LANES(j, c.num_height_points) sh.heights[j] = B.d_measured_heights ? B.d_measured_heights[(size_t)env * c.num_height_points + j] : 0.0f;
+      PF_SYNC();
+      observations(sh, c, L, B, inj, env, g.step_counter);
+      return;
+    }
+    PF_LANES(k, c.num_actions) S[L.actions + k] = pf_clip(g.actions[(size_t)env * c.num_actions + k], -c.clip_actions, c.clip_actions);   // :176-177
+    PF_SYNC();
+    if (inj.d_root) {
+      // Python-layer parity mode: injected sim snapshots stand in for simulate()/refresh (:183-185, :200-202)
+      torques(sh, c, L, inj.d_dof_pre + (size_t)env * ND * 2, 2, 1);
+      PF_LANES(k, ND) { S[L.dof_pos + k] = inj.d_dof_post[((size_t)env * ND + k) * 2]; S[L.dof_vel + k] = inj.d_dof_post[((size_t)env * ND + k) * 2 + 1]; }
+      PF_LANES(i, 13) S[L.root + i] = inj.d_root[(size_t)env * 13 + i];
+      PF_LANES(i, NB * 3) S[L.contact_forces + i] = inj.d_contact[(size_t)env * NB * 3 + i];
+      PF_LANES(i, NF * 3) S[L.feet_pos + i] = inj.d_feet_pos[(size_t)env * NF * 3 + i];
+      PF_SYNC();
+    } else {
+      for (int sub = 0; sub < c.decimation; ++sub) {     // :180-185
+        torques(sh, c, L, S + L.dof_pos, 1, L.dof_vel - L.dof_pos);
+        bool ext = sub == 0 && S[L.ext_force + 3] != 0.0f;
+        substep(sh, m, c, L, B, ext);
+        if (ext) { PF_ONE { S[L.ext_force + 3] = 0.0f; } PF_SYNC(); }
+      }
+      kinematics<false>(sh, m, c, L);
+      PF_LANES(e, NF * 3) { int f = e / 3, t = e - 3 * f; S[L.feet_pos + e] = S[L.root + t] + sh.r[m.feet_body[f]][t]; }
+      PF_SYNC();
+    }
+    post_physics(sh, m, c, L, B, inj, env, g.step_counter);
+    PF_LANES(i, L.rec_floats) grow[i] = S[i];
+  }
+
+  // ------------------------------------------------------------------ post_physics_step (:195-230)
+  PF_DEV void post_physics(Shared& sh, const PfModel& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+    float* S = sh.rec;
+    const int H = c.num_height_points;
+    long long ep = B.d_episode_length[env] + 1;      // :204
+    float q[4] = {S[L.root + 3], S[L.root + 4], S[L.root + 5], S[L.root + 6]};
+    // :208-211 (uniform; lane 0 stores)
+    float blv[3], bav[3], pg[3];
+    {
+      float lv[3] = {S[L.root + 7], S[L.root + 8], S[L.root + 9]}, av[3] = {S[L.root + 10], S[L.root + 11], S[L.root + 12]}, gv[3] = {0.0f, 0.0f, -1.0f};
+      pf_quat_rotate_dir(q, lv, -1.0f, blv); pf_quat_rotate_dir(q, av, -1.0f, bav); pf_quat_rotate_dir(q, gv, -1.0f, pg);
+    }
+    // :212-213, :1048-1075 height scan — one point per lane
+    float root_z = S[L.root + 2];
+    float hsum = 0.0f;
+    if (c.measure_heights) {
+      float qy[4] = {0.0f, 0.0f, q[2], q[3]};
+      float nrm = sqrtf(qy[2] * qy[2] + qy[3] * qy[3]);
+      nrm = nrm < 1e-9f ? 1e-9f : nrm;
+      qy[2] /= nrm; qy[3] /= nrm;
+      PF_LANES(j, H) {
+        float hv = 0.0f;
+        if (c.terrain_type != PF_TERRAIN_PLANE) {
+          float pl[3] = {c.height_px[j], c.height_py[j], 0.0f}, pw[3];
+          pf_quat_apply(qy, pl, pw);
+          hv = height_raw(c, B.d_height_samples, pw[0] + S[L.root], pw[1] + S[L.root + 1]) * c.vscale;
+        }
+        sh.heights[j] = hv;
+        if (B.d_measured_heights) B.d_measured_heights[(size_t)env * H + j] = hv;
+        hsum += root_z - hv;
+      }
+      hsum = PF_WAVE_SUM(hsum);
+    }
+    // :1114-1129 feet state machine
+    PF_LANES(f, NF) {
+      bool first = S[L.first_contact + f] != 0.0f, filt = S[L.contact_filt + f] != 0.0f;
+      float air = S[L.feet_air_time + f];
+      S[L.last_feet_air_time + f] = first ? air : S[L.last_feet_air_time + f];
+      if (filt) air = 0.0f * air;
+      if (c.include_feet_height) {
+        float cm = S[L.cur_max_feet_height + f];
+        S[L.last_max_feet_height + f] = first ? cm : S[L.last_max_feet_height + f];
+        if (filt) cm = 0.0f * cm;
+        float hb = 0.0f;
+        if (c.terrain_type != PF_TERRAIN_PLANE) hb = height_raw(c, B.d_height_samples, S[L.feet_pos + 3 * f], S[L.feet_pos + 3 * f + 1]) * c.vscale;
+        float fh = S[L.feet_pos + 3 * f + 2] - hb;
+        S[L.feet_height + f] = fh;
+        S[L.cur_max_feet_height + f] = fmaxf(cm, fh);
+      }
+      bool contact = S[L.contact_forces + 3 * m.feet_body[f] + 2] > 1.0f;
+      bool nfilt = contact || (S[L.last_contacts + f] != 0.0f);
+      S[L.contact_filt + f] = nfilt ? 1.0f : 0.0f;
+      S[L.last_contacts + f] = contact ? 1.0f : 0.0f;
+      S[L.first_contact + f] = (air > 0.0f && nfilt) ? 1.0f : 0.0f;
+      S[L.feet_air_time + f] = air + c.dt;
+    }
+    // :479-493 callback
+    float cmd2 = S[L.commands + 2];
+    if (c.heading_command) {
+      float fwd[3] = {1.0f, 0.0f, 0.0f}, fw[3];
+      pf_quat_apply(q, fwd, fw);
+      float heading = atan2f(fw[1], fw[0]);
+      cmd2 = pf_clip(0.5f * pf_wrap_to_pi(S[L.commands + 3] - heading), -1.0f, 1.0f);
+    }
+    bool push = c.push_robots && (step % c.push_interval == 0);
+    float ef[3] = {0.0f, 0.0f, 0.0f};
+    if (push) {     // :590-611
+      float fr[3];
+      for (int i = 0; i < 3; ++i) fr[i] = (c.max_push_force - (-c.max_push_force)) * rnd(c, L, inj, env, step, L.r_push + i) + (-c.max_push_force);
+      pf_quat_rotate_dir(q, fr, 1.0f, ef);
+      ef[2] *= 0.5f;
+    }
+    PF_SYNC();
+    PF_ONE {
+      for (int t = 0; t < 3; ++t) { S[L.base_lin_vel + t] = blv[t]; S[L.base_ang_vel + t] = bav[t]; S[L.projected_gravity + t] = pg[t]; }
+      S[L.commands + 2] = cmd2;
+      if (push) { S[L.ext_force] = ef[0]; S[L.ext_force + 1] = ef[1]; S[L.ext_force + 2] = ef[2]; S[L.ext_force + 3] = 1.0f; }
+    }
+    PF_SYNC();
+    // :239-247 termination (uniform)
+    bool term = false;
+    for (int t = 0; t < m.n_term; ++t) {
+      const float* Fc = S + L.contact_forces + 3 * m.term_body[t];
+      term = term || (sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1] + Fc[2] * Fc[2]) > 1.0f);
+    }
+    bool time_out = (float)ep > c.max_episode_length;
+    bool reset = term || time_out;
+    // :301-318 rewards (uniform; every lane computes the same scalars)
+    float rew = 0.0f;
+    for (int ri = 0; ri < c.num_rewards; ++ri) {
+      float v = 0.0f;
+      switch (c.reward_id[ri]) {
+        case PF_REW_LIN_VEL_Z: v = blv[2] * blv[2]; break;
+        case PF_REW_ANG_VEL_XY: v = bav[0] * bav[0] + bav[1] * bav[1]; break;
+        case PF_REW_ORIENTATION: v = pg[0] * pg[0] + pg[1] * pg[1]; break;
+        case PF_REW_BASE_HEIGHT: { float bh = c.measure_heights ? hsum / (float)H : root_z; v = (bh - c.base_height_target) * (bh - c.base_height_target); } break;
+        case PF_REW_TORQUES: for (int k = 0; k < ND; ++k) v += S[L.torques + k] * S[L.torques + k]; break;
+        case PF_REW_DOF_VEL: for (int k = 0; k < ND; ++k) v += S[L.dof_vel + k] * S[L.dof_vel + k]; break;
+        case PF_REW_DOF_ACC: for (int k = 0; k < ND; ++k) { float a = (S[L.last_dof_vel + k] - S[L.dof_vel + k]) / c.dt; v += a * a; } break;
+        case PF_REW_ACTION_RATE: for (int k = 0; k < c.num_actions; ++k) { float a = S[L.last_actions + k] - S[L.actions + k]; v += a * a; } break;
+        case PF_REW_COLLISION:
+          for (int t = 0; t < m.n_pen; ++t) { const float* Fc = S + L.contact_forces + 3 * m.pen_body[t]; v += (sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1] + Fc[2] * Fc[2]) > 0.1f) ? 1.0f : 0.0f; }
+          break;
+        case PF_REW_TERMINATION: v = (reset && !time_out) ? 1.0f : 0.0f; break;
+        case PF_REW_DOF_POS_LIMITS:
+          for (int k = 0; k < ND; ++k) { float o = -fminf(S[L.dof_pos + k] - c.dof_pos_soft_lo[k], 0.0f); o += fmaxf(S[L.dof_pos + k] - c.dof_pos_soft_hi[k], 0.0f); v += o; }
+          break;
+        case PF_REW_DOF_VEL_LIMITS: for (int k = 0; k < ND; ++k) v += pf_clip(fabsf(S[L.dof_vel + k]) - c.dof_vel_limits[k] * c.soft_dof_vel_limit, 0.0f, 1.0f); break;
+        case PF_REW_TORQUE_LIMITS: for (int k = 0; k < ND; ++k) v += fmaxf(fabsf(S[L.torques + k]) - c.torque_limits[k] * c.soft_torque_limit, 0.0f); break;
+        case PF_REW_TRACKING_LIN_VEL: { float ex = S[L.commands] - blv[0], ey = S[L.commands + 1] - blv[1]; v = expf(-(ex * ex + ey * ey) / c.tracking_sigma); } break;
+        case PF_REW_TRACKING_ANG_VEL: { float e = cmd2 - bav[2]; v = expf(-(e * e) / c.tracking_sigma); } break;
+        case PF_REW_FEET_AIR_TIME: {
+          float lo = 0.0f, hi = 0.0f;
+          for (int f = 0; f < NF; ++f) { float fc = S[L.first_contact + f], at = S[L.feet_air_time + f]; lo += fminf(at - c.min_feet_air_time, 0.0f) * fc; hi += fminf(c.max_feet_air_time - at, 0.0f) * fc; }
+          v = lo + hi;
+        } break;
+        case PF_REW_NO_FLY: { float n = 0.0f; for (int f = 0; f < NF; ++f) n += (S[L.contact_forces + 3 * m.feet_body[f] + 2] > 0.1f) ? 1.0f : 0.0f; v = (n == 1.0f) ? 1.0f : 0.0f; } break;
+        case PF_REW_UNBALANCE_FEET_AIR_TIME:
+        case PF_REW_UNBALANCE_FEET_HEIGHT: {
+          const float* a = S + (c.reward_id[ri] == PF_REW_UNBALANCE_FEET_AIR_TIME ? L.last_feet_air_time : L.last_max_feet_height);
+          float mean = 0.0f; for (int f = 0; f < NF; ++f) mean += a[f]; mean /= (float)NF;
+          float s = 0.0f; for (int f = 0; f < NF; ++f) s += (a[f] - mean) * (a[f] - mean);
+          v = s / (float)(NF - 1);
+        } break;
+        case PF_REW_STUMBLE:
+          for (int f = 0; f < NF; ++f) { const float* Fc = S + L.contact_forces + 3 * m.feet_body[f]; if (sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1]) > 5.0f * fabsf(Fc[2])) v = 1.0f; }
+          break;
+        case PF_REW_STAND_STILL:
+          v = (fabsf(blv[0]) * (S[L.commands] < 0.1f ? 1.0f : 0.0f) + fabsf(blv[1]) * (S[L.commands + 1] < 0.1f ? 1.0f : 0.0f)) + fabsf(bav[2]) * (cmd2 < 0.1f ? 1.0f : 0.0f);
+          break;
+        case PF_REW_FEET_CONTACT_FORCES:
+          for (int f = 0; f < NF; ++f) { const float* Fc = S + L.contact_forces + 3 * m.feet_body[f]; v += fmaxf(sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1] + Fc[2] * Fc[2]) - c.max_contact_force, 0.0f); }
+          break;
+        case PF_REW_FEET_DISTANCE:
+          for (int i = 0; i < NF - 1; ++i) {
+            int j = NF - 1;
+            float dx = S[L.feet_pos + 3 * i] - S[L.feet_pos + 3 * j], dy = S[L.feet_pos + 3 * i + 1] - S[L.feet_pos + 3 * j + 1];
+            v += pf_clip(c.min_feet_distance - sqrtf(dx * dx + dy * dy), 0.0f, 1.0f);
+          }
+          break;
+        case PF_REW_SURVIVAL: v = (reset ? 0.0f : 1.0f) * c.dt; break;
+        default: break;
+      }
+      float r = v * c.reward_scale[ri];
+      rew += r;
+      if (PF_LANE_ID == 0) S[L.episode_sums + ri] += r;
+    }
+    if (c.only_positive_rewards) rew = fmaxf(rew, 0.0f);
+    if (c.termination_scale != 0.0f) {
+      float r = ((reset && !time_out) ? 1.0f : 0.0f) * c.termination_scale;
+      rew += r;
+      if (PF_LANE_ID == 0) S[L.episode_sums + c.num_rewards] += r;
+    }
+    PF_ONE {
+      B.d_rew[env] = rew; B.d_terminate[env] = term ? 1 : 0; B.d_time_out[env] = time_out ? 1 : 0; B.d_reset[env] = reset ? 1 : 0;
+      B.d_episode_length[env] = reset ? 0 : ep;
+    }
+    PF_SYNC();
+    if (reset) reset_env(sh, m, c, L, B, inj, env, step);      // :221-222 masked reset
+    observations(sh, c, L, B, inj, env, step);                  // :223
+    PF_SYNC();
+    PF_LANES(k, c.num_actions) S[L.last_actions + k] = S[L.actions + k];    // :225-227
+    PF_LANES(k, ND) S[L.last_dof_vel + k] = S[L.dof_vel + k];
+    PF_LANES(i, 6) S[L.last_root_vel + i] = S[L.root + 7 + i];
+    PF_SYNC();
+  }
+};

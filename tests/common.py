@@ -1,0 +1,198 @@
+"""Shared test plumbing: builds/loads the CPU oracle and the host-emulation build of the HIP step
+program, and drives either (or the real HIP library) through the same PfBuffers/PfInject structs on the
+golden fixtures.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from pointfoot_amd import _abi  # noqa: E402
+from pointfoot_amd.envs.pointfoot import _native  # noqa: E402
+from pointfoot_amd.utils.helpers import SimParams  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _build(cmd, out, srcs):
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+        return
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(cmd, cwd=ROOT)
+
+
+def oracle_lib():
+    out = os.path.join(ROOT, "oracle", "_build", "libpf_oracle.so")
+    srcs = [os.path.join(ROOT, "oracle", "pf_oracle.cpp"), os.path.join(ROOT, "oracle", "philox.h"),
+            os.path.join(ROOT, "include", "pointfoot_hip.h")]
+    _build(["make", "-s", "-C", "oracle"], out, srcs)
+    lib = C.CDLL(out)
+    lib.pfo_step.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfConfig), C.POINTER(_abi.PfLayout),
+                             C.POINTER(_abi.PfBuffers), C.c_void_p, C.c_int64, C.POINTER(_abi.PfInject), C.c_int]
+    lib.pfo_energy.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfConfig), C.POINTER(_abi.PfLayout),
+                               C.c_void_p, C.POINTER(C.c_double)]
+    lib.pfo_set_threads.argtypes = [C.c_int]
+    return lib
+
+
+def emu_lib():
+    out = os.path.join(ROOT, "tests", "emu", "_build", "libpf_emu.so")
+    srcs = [os.path.join(ROOT, "tests", "emu", "pf_emu.cpp")] + [
+        os.path.join(ROOT, "pointfoot_amd", "csrc", f) for f in ("pf_step_kernel.h", "pf_simt.h", "pf_layout.h")] + [
+        os.path.join(ROOT, "include", "pointfoot_hip.h")]
+    _build(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "tests/emu/pf_emu.cpp", "-o", out],
+           out, srcs)
+    lib = C.CDLL(out)
+    lib.pfe_step.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfConfig), C.POINTER(_abi.PfLayout),
+                             C.POINTER(_abi.PfBuffers), C.c_void_p, C.c_longlong, C.POINTER(_abi.PfInject), C.c_int]
+    lib.pfe_layout.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfConfig), C.POINTER(_abi.PfLayout)]
+    return lib
+
+
+def make_cfg(task, num_envs, control_type="P", add_noise=True):
+    from pointfoot_amd.envs.pointfoot.mixed_terrain.pointfoot_rough_config import PointFootRoughCfg
+    from pointfoot_amd.envs.pointfoot.flat.pointfoot_flat_config import PointFootFlatCfg
+    cfg = PointFootRoughCfg() if task == "rough" else PointFootFlatCfg()
+    cfg.env.num_envs = num_envs
+    cfg.control.control_type = control_type
+    cfg.noise.add_noise = add_noise
+    return cfg
+
+
+class HostSim:
+    """Numpy-backed PfBuffers + state record, steppable by the oracle or the emu build."""
+
+    def __init__(self, cfg, n, hf=None, terrain_origins=None, mean_base_mass=None, seed=1):
+        self.cfg = cfg
+        self.n = n
+        sp = SimParams(dt=cfg.sim.dt)
+        self.model, self.info = _native.build_model(cfg)
+        self.c, self.reward_names = _native.build_config(
+            cfg, self.model, self.info, sp, n, hf_shape=None if hf is None else hf.shape,
+            mean_base_mass=mean_base_mass, seed=seed)
+        self.L = _abi.PfLayout()
+        assert emu_lib().pfe_layout(C.byref(self.model), C.byref(self.c), C.byref(self.L)) == 0
+        L = self.L
+        self.state = np.zeros((n, L.rec_floats), np.float32)
+        self.state[:, L.root + 6] = 1.0
+        self.episode_length = np.zeros(n, np.int64)
+        self.terrain_level = np.zeros(n, np.int32)
+        self.terrain_type = np.zeros(n, np.int32)
+        self.reset = np.zeros(n, np.uint8)
+        self.time_out = np.zeros(n, np.uint8)
+        self.terminate = np.zeros(n, np.uint8)
+        self.obs = np.zeros((n, self.c.num_obs), np.float32)
+        self.priv = np.zeros((n, max(self.c.num_priv_obs, 1)), np.float32)
+        self.rew = np.zeros(n, np.float32)
+        self.heights = np.zeros((n, max(self.c.num_height_points, 1)), np.float32)
+        self.hf = None if hf is None else np.ascontiguousarray(hf, np.int16)
+        self.terrain_origins = None if terrain_origins is None else np.ascontiguousarray(terrain_origins, np.float32)
+        self.stats = np.zeros(_abi.PF_STATS_FLOATS, np.float32)
+        self.bufs = self.make_bufs()
+
+    def make_bufs(self):
+        p = _native.ptr
+        b = _abi.PfBuffers()
+        b.d_state, b.d_episode_length = p(self.state), p(self.episode_length)
+        b.d_terrain_level, b.d_terrain_type = p(self.terrain_level), p(self.terrain_type)
+        b.d_reset, b.d_time_out, b.d_terminate = p(self.reset), p(self.time_out), p(self.terminate)
+        b.d_obs, b.d_priv, b.d_rew = p(self.obs), p(self.priv), p(self.rew)
+        b.d_measured_heights = p(self.heights)
+        b.d_height_samples = p(self.hf)
+        b.d_terrain_origins = p(self.terrain_origins)
+        b.d_reset_stats = p(self.stats)
+        return b
+
+    def f(self, name, width=None):
+        """view of a record field"""
+        o = getattr(self.L, name)
+        return self.state[:, o:o + width] if width else self.state[:, o]
+
+    def clone(self):
+        import copy
+        other = copy.copy(self)
+        for k in ("state", "episode_length", "terrain_level", "terrain_type", "reset", "time_out", "terminate", "obs",
+                  "priv", "rew", "heights", "stats"):
+            setattr(other, k, getattr(self, k).copy())
+        other.bufs = other.make_bufs()
+        return other
+
+    def step(self, backend, actions, counter, inject=None, physics_bits=32, mode=0):
+        actions = np.ascontiguousarray(actions, np.float32)
+        inj = inject if inject is not None else None
+        if backend == "oracle":
+            assert mode == 0
+            rc = oracle_lib().pfo_step(C.byref(self.model), C.byref(self.c), C.byref(self.L), C.byref(self.bufs),
+                                       actions.ctypes.data, counter, inj, physics_bits)
+        elif backend == "emu":
+            rc = emu_lib().pfe_step(C.byref(self.model), C.byref(self.c), C.byref(self.L), C.byref(self.bufs),
+                                    actions.ctypes.data, counter, inj, mode)
+        else:
+            raise ValueError(backend)
+        assert rc == 0
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def sim_from_golden(g, task, control_type="P", add_noise=True):
+    """HostSim initialised to the golden file's `init_*` snapshot."""
+    import synth
+    n = g["init_root"].shape[0]
+    cfg = make_cfg(task, n, control_type, add_noise)
+    rough = task == "rough"
+    hf = synth.synth_heightfield() if rough else None
+    to = g["terrain_origins"] if rough else None
+    sim = HostSim(cfg, n, hf=hf, terrain_origins=to, mean_base_mass=float(g["base_mass"].mean(dtype=np.float32)))
+    L = sim.L
+    nd, nf = 6, 2
+    sim.f("root", 13)[:] = g["init_root"]
+    sim.f("dof_pos", nd)[:] = g["init_dof"][:, :, 0]
+    sim.f("dof_vel", nd)[:] = g["init_dof"][:, :, 1]
+    sim.f("commands", 4)[:, :g["init_commands"].shape[1]] = g["init_commands"]
+    sim.f("last_actions", nd)[:] = g["init_last_actions"]
+    sim.f("last_dof_vel", nd)[:] = g["init_last_dof_vel"]
+    for name in ("feet_air_time", "last_feet_air_time", "contact_filt", "first_contact", "last_contacts", "feet_height",
+                 "last_max_feet_height"):
+        sim.f(name, nf)[:] = g["init_" + name].astype(np.float32)
+    sim.f("cur_max_feet_height", nf)[:] = g["init_current_max_feet_height"]
+    R = len(g["reward_names"])
+    sim.f("episode_sums", R)[:] = g["init_episode_sums"].T
+    sim.f("env_origin", 3)[:] = g["init_env_origins"]
+    sim.episode_length[:] = g["init_episode_length"]
+    if rough:
+        sim.terrain_level[:] = g["init_terrain_levels"]
+        sim.terrain_type[:] = g["terrain_types"]
+    return sim
+
+
+def inject_from_golden(g, t, sim, keep):
+    """PfInject for golden step t (arrays are appended to `keep` to stay alive)."""
+    L = sim.L
+    n = sim.n
+    p = f"s{t}"
+    rnd = np.zeros((n, L.rand_floats), np.float32)
+    rnd[:, L.r_obs:L.r_obs + 27] = g[p + "_r_obs"]
+    rp = g[p + "_r_priv"]
+    if rp.shape[1]:
+        rnd[:, L.r_priv:L.r_priv + rp.shape[1]] = rp
+    rnd[:, L.r_dof:L.r_dof + 6] = g[p + "_r_dof"]
+    rnd[:, L.r_xy:L.r_xy + 2] = g[p + "_r_xy"]
+    rnd[:, L.r_vel:L.r_vel + 6] = g[p + "_r_vel"]
+    rnd[:, L.r_level] = np.maximum(g[p + "_r_level"], 0)
+    rnd[:, L.r_push:L.r_push + 3] = g[p + "_r_push"]
+    arrs = dict(d_rand=rnd, d_dof_pre=np.ascontiguousarray(g[p + "_dof_pre"]),
+                d_dof_post=np.ascontiguousarray(g[p + "_dof_post"]), d_root=np.ascontiguousarray(g[p + "_sim_root"]),
+                d_contact=np.ascontiguousarray(g[p + "_sim_contact"]),
+                d_feet_pos=np.ascontiguousarray(g[p + "_sim_feet_pos"]))
+    inj = _abi.PfInject()
+    for k, a in arrs.items():
+        setattr(inj, k, _native.ptr(a))
+    keep.append(arrs)
+    return inj, arrs

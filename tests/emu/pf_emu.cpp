@@ -1,0 +1,21 @@
+// TEST INFRASTRUCTURE — host emulation build of the HIP env-step program (pf_step_kernel.h compiled
+// with -DPF_HOST_EMU: lane loops become serial loops).  Lets the CPU test-suite exercise the very
+// source the GPU runs.  Never linked into the product library.
+#define PF_HOST_EMU 1
+#include "../../pointfoot_amd/csrc/pf_step_kernel.h"
+#include "../../pointfoot_amd/csrc/pf_layout.h"
+
+extern "C" int pfe_step(const PfModel* model, const PfConfig* cfg, const PfLayout* layout, const PfBuffers* bufs,
+                        const float* actions, long long step_counter, const PfInject* inject, int mode) {
+  if (!(model->nb == 9 && model->nd == 6 && model->nfeet == 2)) return 1;
+  using K = PfKernel<9, 6, 2>;
+  static K::Shared sh;
+  PfStepArgs g;
+  g.model = model; g.cfg = cfg; g.L = *layout; g.b = *bufs;
+  if (inject) g.inj = *inject; else std::memset(&g.inj, 0, sizeof(g.inj));
+  g.actions = actions; g.step_counter = step_counter; g.mode = mode;
+  if (bufs->d_reset_stats && mode != 2) std::memset(bufs->d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS);
+  for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, g, env);
+  return 0;
+}
+extern "C" int pfe_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out) { return pf_compute_layout(model, cfg, out); }
