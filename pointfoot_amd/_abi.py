@@ -157,6 +157,15 @@ def load():
     lib.pf_step.argtypes = [vp, vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_reset_all.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_compute_observations.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
+    if hasattr(lib, 'ppo_create'):   # TEMP until pf_ppo.hip lands
+        _bind_ppo(lib)
+    for fn in ("pf_bind_buffers", "pf_update_config", "pf_step", "pf_reset_all", "pf_compute_observations"):
+        getattr(lib, fn).restype = i32
+    _LIB = lib
+    return lib
+
+
+def _bind_ppo(lib):
     lib.ppo_create.argtypes = [C.POINTER(PpoConfig), i32]
     lib.ppo_create.restype = vp
     lib.ppo_destroy.argtypes = [vp]
@@ -172,12 +181,9 @@ def load():
     lib.ppo_normalize_advantages.argtypes = [vp, vp]
     lib.ppo_minibatch_backward.argtypes = [vp, i32, vp]
     lib.ppo_minibatch_apply.argtypes = [vp, vp]
-    for fn in ("pf_bind_buffers", "pf_update_config", "pf_step", "pf_reset_all", "pf_compute_observations",
-               "ppo_bind_buffers", "ppo_act", "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns",
+    for fn in ("ppo_bind_buffers", "ppo_act", "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns",
                "ppo_normalize_advantages", "ppo_minibatch_backward", "ppo_minibatch_apply"):
         getattr(lib, fn).restype = i32
-    _LIB = lib
-    return lib
 
 
 def check(rc, lib=None):

@@ -46,6 +46,12 @@ extern "C" {
 
 const char* pf_last_error(void) { return g_pf_error.c_str(); }
 
+void pf_abi_sizes(int64_t* sizes, int32_t n) {
+  const int64_t v[7] = {sizeof(PfModel), sizeof(PfConfig), sizeof(PfLayout), sizeof(PfBuffers), sizeof(PfInject),
+                        sizeof(PpoConfig), sizeof(PpoBuffers)};
+  for (int i = 0; i < n && i < 7; ++i) sizes[i] = v[i];
+}
+
 int pf_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out) {
   if (!model || !cfg || !out) { pf_set_error("pf_layout: null argument"); return 1; }
   pf_compute_layout(model, cfg, out);

@@ -196,3 +196,70 @@ def inject_from_golden(g, t, sim, keep):
         setattr(inj, k, _native.ptr(a))
     keep.append(arrs)
     return inj, arrs
+
+
+class HipMirror:
+    """Runs a HostSim's buffers through the real HIP library: upload -> pf_step -> download."""
+    FIELDS = ("state", "episode_length", "terrain_level", "terrain_type", "reset", "time_out", "terminate", "obs",
+              "priv", "rew", "heights", "stats")
+
+    def __init__(self, sim, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.sim = sim
+        self.dev = device
+        self.lib = _abi.load()
+        self.t = {}
+        for k in self.FIELDS:
+            self.t[k] = torch.from_numpy(getattr(sim, k).copy()).to(device)
+        self.t["hf"] = None if sim.hf is None else torch.from_numpy(sim.hf).to(device)
+        self.t["to"] = None if sim.terrain_origins is None else torch.from_numpy(sim.terrain_origins).to(device)
+        self.h = self.lib.pf_create(C.byref(sim.model), C.byref(sim.c), 0)
+        assert self.h, self.lib.pf_last_error()
+        p = _native.ptr
+        b = _abi.PfBuffers()
+        t = self.t
+        b.d_state, b.d_episode_length = p(t["state"]), p(t["episode_length"])
+        b.d_terrain_level, b.d_terrain_type = p(t["terrain_level"]), p(t["terrain_type"])
+        b.d_reset, b.d_time_out, b.d_terminate = p(t["reset"]), p(t["time_out"]), p(t["terminate"])
+        b.d_obs, b.d_priv, b.d_rew = p(t["obs"]), p(t["priv"]), p(t["rew"])
+        b.d_measured_heights = p(t["heights"])
+        b.d_height_samples, b.d_terrain_origins = p(t["hf"]), p(t["to"])
+        b.d_reset_stats = p(t["stats"])
+        self.b = b
+        _abi.check(self.lib.pf_bind_buffers(self.h, C.byref(b)), self.lib)
+        Lh = _abi.PfLayout()
+        _abi.check(self.lib.pf_layout(C.byref(sim.model), C.byref(sim.c), C.byref(Lh)), self.lib)
+        assert bytes(Lh) == bytes(sim.L), "pf_layout (HIP library) disagrees with the test layout"
+
+    def upload(self):
+        for k in self.FIELDS:
+            self.t[k].copy_(self.torch.from_numpy(getattr(self.sim, k)))
+
+    def download(self):
+        self.torch.cuda.synchronize()
+        for k in self.FIELDS:
+            getattr(self.sim, k)[...] = self.t[k].cpu().numpy()
+
+    def step(self, actions, counter, inject_arrays=None, mode=0):
+        torch = self.torch
+        a = torch.from_numpy(np.ascontiguousarray(actions, np.float32)).to(self.dev)
+        inj = None
+        keep = []
+        if inject_arrays is not None:
+            inj = _abi.PfInject()
+            for k, arr in inject_arrays.items():
+                tt = torch.from_numpy(arr).to(self.dev)
+                keep.append(tt)
+                setattr(inj, k, _native.ptr(tt))
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        fn = {0: lambda: self.lib.pf_step(self.h, a.data_ptr(), counter, inj, stream),
+              1: lambda: self.lib.pf_reset_all(self.h, counter, inj, stream),
+              2: lambda: self.lib.pf_compute_observations(self.h, counter, inj, stream)}[mode]
+        _abi.check(fn(), self.lib)
+        self.download()
+
+    def close(self):
+        if self.h:
+            self.lib.pf_destroy(self.h)
+            self.h = None
