@@ -183,12 +183,15 @@ struct PfKernel {
 #pragma clang fp contract(off)
 #endif
     PF_LANES(k, ND) {
+      // branch-free on purpose: hipcc (ROCm 7.2) miscompiled the if / else-if / else form of this body
+      // (lane index left undefined on the 'T' path -> wild load of torque_limits); selects are also cheaper.
       float qp = qsrc[k * qstride], qv = qsrc[k * qstride + voff];
-      float as = sh.rec[L.actions + k] * c.action_scale, t;
-      if (c.control_type == PF_CTRL_P) t = c.p_gains[k] * ((as + c.default_dof_pos[k]) - qp) - c.d_gains[k] * qv;
-      else if (c.control_type == PF_CTRL_V) t = c.p_gains[k] * (as - qv) - c.d_gains[k] * (qv - sh.rec[L.last_dof_vel + k]) / c.sim_dt;
-      else t = as;
-      sh.rec[L.torques + k] = pf_clip(t, -c.torque_limits[k], c.torque_limits[k]);
+      float as = sh.rec[L.actions + k] * c.action_scale;
+      float lim = c.torque_limits[k];
+      float tP = c.p_gains[k] * ((as + c.default_dof_pos[k]) - qp) - c.d_gains[k] * qv;
+      float tV = c.p_gains[k] * (as - qv) - c.d_gains[k] * (qv - sh.rec[L.last_dof_vel + k]) / c.sim_dt;
+      float t = c.control_type == PF_CTRL_P ? tP : (c.control_type == PF_CTRL_V ? tV : as);
+      sh.rec[L.torques + k] = pf_clip(t, -lim, lim);
     }
     PF_SYNC();
   }
