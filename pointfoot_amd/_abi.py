@@ -157,8 +157,7 @@ def load():
     lib.pf_step.argtypes = [vp, vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_reset_all.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_compute_observations.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
-    if hasattr(lib, 'ppo_create'):   # TEMP until pf_ppo.hip lands
-        _bind_ppo(lib)
+    _bind_ppo(lib)
     for fn in ("pf_bind_buffers", "pf_update_config", "pf_step", "pf_reset_all", "pf_compute_observations"):
         getattr(lib, fn).restype = i32
     _LIB = lib

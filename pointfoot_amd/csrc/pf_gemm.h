@@ -1,0 +1,162 @@
+// pf_gemm.h — fp32 MFMA GEMM for the actor-critic MLPs (gfx950: v_mfma_f32_32x32x2_f32, exact f32,
+// 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
+//
+//   C[M,N] = op(A) * op(B)  (+ epilogue), three operand arrangements of an nn.Linear layer y = x W^T + b:
+//     FWD  : C = X[M,K]  * W[N,K]^T      A k-contiguous, B k-contiguous   -> bias + ELU epilogue
+//     BWD_X: C = G[M,K]  * W[K,N]        A k-contiguous, B n-contiguous   -> * ELU'(H) epilogue
+//     BWD_W: C = G[Kr,M]^T * X[Kr,N]     A m-contiguous, B n-contiguous, reduction over rows Kr split across
+//                                         blockIdx.z into slabs (deterministic two-stage reduce, no atomics)
+// Tiling: 256 threads = 4 wavefronts (2x2); block tile BM x BN with BM,BN in {64,128}, BK = 32; each wave owns
+// (BM/2)x(BN/2) = TMxTN tiles of 32x32.  Both operands are staged in LDS k-major (As[k][m], Bs[k][n]) so a
+// fragment read is 32 consecutive floats per half-wave (conflict-free ds_read_b32); row stride +1/+4 padded so the
+// transposing stores of k-contiguous operands are conflict-free too.  The next k-tile is prefetched into
+// registers while the current one feeds the MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { GEMM_EPI_NONE = 0, GEMM_EPI_BIAS = 1, GEMM_EPI_BIAS_ELU = 2, GEMM_EPI_MUL_DELU = 3 };
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K;          // C is M x N, reduction length K
+  int lda, ldb, ldc;    // row strides (floats) of the arrays as stored
+  const float* bias;    // [N]            (EPI_BIAS*)
+  const float* H;       // [M, ldh]       (EPI_MUL_DELU: C *= (H > 0 ? 1 : H + 1))
+  int ldh;
+  int k_per_split;      // BWD_W: rows of the reduction handled per blockIdx.z (multiple of 32); C slab z at C + z*M*ldc
+};
+
+__device__ __forceinline__ float pf_elu(float x) { return x > 0.0f ? x : (__expf(x) - 1.0f); }
+
+// A_KC: A stored [M][K] (k contiguous) else [K][M] (m contiguous).  B_KC: B stored [N][K] else [K][N].
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
+  constexpr int BK = 32;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int LDA_S = BM + (A_KC ? 1 : 4), LDB_S = BN + (B_KC ? 1 : 4);
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int k_begin = 0, k_end = g.K;
+  float* Cout = g.C;
+  if (g.k_per_split > 0) {
+    k_begin = blockIdx.z * g.k_per_split;
+    k_end = min(g.K, k_begin + g.k_per_split);
+    Cout += (size_t)blockIdx.z * g.M * g.ldc;
+  }
+  constexpr int A_V4 = BM * BK / 4 / 256, B_V4 = BN * BK / 4 / 256;   // float4 chunks per thread
+  float4 ra[A_V4], rb[B_V4];
+
+  auto load4 = [&](const float* base, int ld, int row, int col, int nrows, int ncols) -> float4 {
+    // 4 consecutive floats along `col`; zero outside [nrows, ncols)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) {
+      const float* p = base + (size_t)row * ld + col;
+      if (col + 3 < ncols && ((((size_t)p) & 15) == 0)) v = *(const float4*)p;
+      else {
+        if (col < ncols) v.x = p[0];
+        if (col + 1 < ncols) v.y = p[1];
+        if (col + 2 < ncols) v.z = p[2];
+        if (col + 3 < ncols) v.w = p[3];
+      }
+    }
+    return v;
+  };
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) {
+      int idx = tid + 256 * i;
+      if (A_KC) { int r = idx / (BK / 4), c4 = idx % (BK / 4); ra[i] = load4(g.A, g.lda, m0 + r, k0 + c4 * 4, g.M, k_end); }
+      else { int r = idx / (BM / 4), c4 = idx % (BM / 4); ra[i] = load4(g.A, g.lda, k0 + r, m0 + c4 * 4, k_end, g.M); }
+    }
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) {
+      int idx = tid + 256 * i;
+      if (B_KC) { int r = idx / (BK / 4), c4 = idx % (BK / 4); rb[i] = load4(g.B, g.ldb, n0 + r, k0 + c4 * 4, g.N, k_end); }
+      else { int r = idx / (BN / 4), c4 = idx % (BN / 4); rb[i] = load4(g.B, g.ldb, k0 + r, n0 + c4 * 4, k_end, g.N); }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) {
+      int idx = tid + 256 * i;
+      if (A_KC) {
+        int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
+        As[(c + 0) * LDA_S + r] = ra[i].x; As[(c + 1) * LDA_S + r] = ra[i].y;
+        As[(c + 2) * LDA_S + r] = ra[i].z; As[(c + 3) * LDA_S + r] = ra[i].w;
+      } else {
+        int r = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
+        *(float4*)&As[r * LDA_S + c] = ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) {
+      int idx = tid + 256 * i;
+      if (B_KC) {
+        int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
+        Bs[(c + 0) * LDB_S + r] = rb[i].x; Bs[(c + 1) * LDB_S + r] = rb[i].y;
+        Bs[(c + 2) * LDB_S + r] = rb[i].z; Bs[(c + 3) * LDB_S + r] = rb[i].w;
+      } else {
+        int r = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+        *(float4*)&Bs[r * LDB_S + c] = rb[i];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int arow = wr * (BM / 2) + (lane & 31), bcol = wc * (BN / 2) + (lane & 31), kh = lane >> 5;
+  fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    __syncthreads();          // previous tile fully consumed
+    stage();
+    __syncthreads();
+    if (k0 + BK < k_end) fetch(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + kh) * LDA_S + arow + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + kh) * LDB_S + bcol + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int col = n0 + wc * (BN / 2) + 32 * j + (lane & 31);
+      if (col >= g.N) continue;
+      float bv = (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) ? g.bias[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + wr * (BM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (EPI == GEMM_EPI_BIAS_ELU) v = pf_elu(v);
+        if (EPI == GEMM_EPI_MUL_DELU) { float h = g.H[(size_t)row * g.ldh + col]; v *= (h > 0.0f ? 1.0f : h + 1.0f); }
+        Cout[(size_t)row * g.ldc + col] = v;
+      }
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+static inline void pf_gemm_launch(const GemmArgs& g, int splits, hipStream_t s) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits > 0 ? splits : 1);
+  hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI>), grid, dim3(256), 0, s, g);
+}

@@ -1,0 +1,634 @@
+// pf_ppo.hip — PPO rollout / GAE / minibatch update kernels + the ppo_* half of the C ABI.
+//
+// Replaces rsl_rl v1.0.2 (un-vendored dependency of the reference; call sites legged_gym/utils/task_registry.py:147,
+// legged_gym/scripts/train.py:44): ActorCritic.act/evaluate, RolloutStorage.add_transitions/compute_returns/
+// mini_batch_generator, PPO.update (SURVEY.md Appendix B lists the semantics restated here).
+// Dense layers run on the fp32 MFMA GEMM of pf_gemm.h; everything else is small fused elementwise/reduction kernels.
+// All reductions are two-stage and atomic-free, so an update is bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pointfoot_hip.h"
+#include "pf_gemm.h"
+
+void pf_set_error(const std::string& s);
+
+#define PPO_HIP_OK(expr)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) { pf_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return 1; } \
+  } while (0)
+
+// scalar slots in d_scalars
+enum { SC_LR = 0, SC_KL = 1, SC_GNORM = 2, SC_VLOSS = 3, SC_SLOSS = 4, SC_STEP = 5, SC_ADV_MEAN = 6, SC_ADV_STD = 7,
+       SC_CLIPCOEF = 8, SC_NUPD = 9, SC_ADV_SUM = 10, SC_ADV_SUMSQ = 11, SC_ADV_CNT = 12, SC_ENTROPY = 13 };
+
+namespace {
+
+struct Layer { int in, out; size_t w, b; };   // offsets into the flat parameter buffer
+
+struct Net {
+  int nl = 0;
+  Layer l[PPO_MAX_LAYERS];
+};
+
+constexpr int RED_BLOCKS = 240;     // stage-1 blocks of every two-stage reduction
+
+// ------------------------------------------------------------------------------------- philox / normal
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* o) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// ------------------------------------------------------------------------------------- rollout
+// Normal(mu, std).sample(), log_prob, store the transition (PPO.act + RolloutStorage.add_transitions)
+__global__ void k_sample(int N, int A, int O, int P, const float* __restrict__ obs, const float* __restrict__ cobs,
+                         const float* __restrict__ mean, const float* __restrict__ value, const float* __restrict__ stdp,
+                         const float* __restrict__ inject_normal, uint32_t k0, uint32_t k1, uint32_t counter, uint32_t env_base,
+                         float* __restrict__ actions_out, float* __restrict__ s_obs, float* __restrict__ s_cobs,
+                         float* __restrict__ s_act, float* __restrict__ s_val, float* __restrict__ s_logp,
+                         float* __restrict__ s_mu, float* __restrict__ s_sigma) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float lp = 0.0f;
+  for (int k = 0; k < A; ++k) {
+    float z;
+    if (inject_normal) z = inject_normal[(size_t)i * A + k];
+    else {
+      uint32_t r[4];
+      philox4(env_base + (uint32_t)i, counter, 1u, (uint32_t)k, k0, k1, r);
+      float u1 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+      float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+      z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    }
+    float mu = mean[(size_t)i * A + k], sg = stdp[k];
+    float a = mu + sg * z;
+    float d = (a - mu) / sg;
+    lp += -0.5f * d * d - logf(sg) - 0.91893853320467274178f;
+    actions_out[(size_t)i * A + k] = a;
+    s_act[(size_t)i * A + k] = a; s_mu[(size_t)i * A + k] = mu; s_sigma[(size_t)i * A + k] = sg;
+  }
+  s_val[i] = value[i]; s_logp[i] = lp;
+  for (int k = 0; k < O; ++k) s_obs[(size_t)i * O + k] = obs[(size_t)i * O + k];
+  for (int k = 0; k < P; ++k) s_cobs[(size_t)i * P + k] = cobs[(size_t)i * P + k];
+}
+
+// PPO.process_env_step: bootstrap on time-outs, store reward / done
+__global__ void k_process(int N, float gamma, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
+                          const uint8_t* __restrict__ time_outs, const float* __restrict__ s_val, float* __restrict__ s_rew,
+                          float* __restrict__ s_done) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float r = rew[i];
+  if (time_outs) r += gamma * (s_val[i] * (time_outs[i] ? 1.0f : 0.0f));
+  s_rew[i] = r; s_done[i] = dones[i] ? 1.0f : 0.0f;
+}
+
+// RolloutStorage.compute_returns: GAE reverse scan, one thread per env; advantages = returns - values
+__global__ void k_gae(int N, int T, float gamma, float lam, const float* __restrict__ last_values, const float* __restrict__ values,
+                      const float* __restrict__ rewards, const float* __restrict__ dones, float* __restrict__ returns,
+                      float* __restrict__ adv) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float a = 0.0f;
+  for (int t = T - 1; t >= 0; --t) {
+    float nv = t == T - 1 ? last_values[i] : values[(size_t)(t + 1) * N + i];
+    float nnt = 1.0f - dones[(size_t)t * N + i];
+    float v = values[(size_t)t * N + i];
+    float delta = rewards[(size_t)t * N + i] + nnt * gamma * nv - v;
+    a = delta + nnt * gamma * lam * a;
+    float ret = a + v;
+    returns[(size_t)t * N + i] = ret;
+    adv[(size_t)t * N + i] = ret - v;
+  }
+}
+
+// ------------------------------------------------------------------------------------- reductions
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float s = 0.0f;
+  for (int i = 0; i < nw; ++i) s += sm[i];
+  return s;
+}
+
+// stage 1: partial[b][0..1] = sum, sumsq over a strided slice
+__global__ void k_moments1(size_t n, const float* __restrict__ x, float* __restrict__ partial) {
+  __shared__ float sm[8];
+  float s = 0.0f, q = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { float v = x[i]; s += v; q += v * v; }
+  s = block_sum(s, sm); q = block_sum(q, sm);
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s; partial[2 * blockIdx.x + 1] = q; }
+}
+__global__ void k_moments2(int nb, size_t n, const float* __restrict__ partial, float* __restrict__ scalars) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nb; ++b) { s += partial[2 * b]; q += partial[2 * b + 1]; }
+    scalars[SC_ADV_SUM] = (float)s; scalars[SC_ADV_SUMSQ] = (float)q; scalars[SC_ADV_CNT] = (float)n;
+  }
+}
+// advantages = (adv - mean) / (std + 1e-8), torch.std is unbiased; sums may have been all-reduced by the host
+__global__ void k_normalize(size_t n, float* __restrict__ x, float* __restrict__ scalars) {
+  float cnt = scalars[SC_ADV_CNT], s = scalars[SC_ADV_SUM], q = scalars[SC_ADV_SUMSQ];
+  float mean = s / cnt;
+  float var = fmaxf((q - cnt * mean * mean) / (cnt - 1.0f), 0.0f);
+  float sd = sqrtf(var);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = (x[i] - mean) / (sd + 1e-8f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scalars[SC_ADV_MEAN] = mean; scalars[SC_ADV_STD] = sd; }
+}
+
+// out[i] (+)= sum_s slabs[s][i]
+__global__ void k_reduce_slabs(int n, int S, const float* __restrict__ slabs, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.0f;
+  for (int k = 0; k < S; ++k) s += slabs[(size_t)k * n + i];
+  out[i] = s;
+}
+
+// column sums of G[M, N] (bias gradients): stage 1 -> slabs[chunk][n]
+__global__ void k_colsum1(int M, int N, int ld, int rows_per_block, const float* __restrict__ G, float* __restrict__ slabs) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s = 0.0f;
+  for (int r = r0; r < r1; ++r) s += G[(size_t)r * ld + n];
+  slabs[(size_t)blockIdx.y * N + n] = s;
+}
+
+// ------------------------------------------------------------------------------------- minibatch gather
+__global__ void k_gather(int B, int cols, const int* __restrict__ perm, const float* __restrict__ src, float* __restrict__ dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * cols) return;
+  int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+  dst[i] = src[(size_t)perm[r] * cols + c];
+}
+
+// ------------------------------------------------------------------------------------- thin output layers (out <= 8)
+// Y[M, NO] = X[M, K] W[NO, K]^T + b     (actor mean / critic value heads)
+template <int NO_MAX>
+__global__ void k_thin_fwd(int M, int K, int NO, const float* __restrict__ X, const float* __restrict__ W,
+                           const float* __restrict__ b, float* __restrict__ Y) {
+  extern __shared__ float sw[];   // NO*K
+  for (int i = threadIdx.x; i < NO * K; i += blockDim.x) sw[i] = W[i];
+  __syncthreads();
+  // 8 lanes cooperate on one row so the row read is one contiguous burst
+  int lane8 = threadIdx.x & 7;
+  int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  if (row >= M) return;
+  float acc[NO_MAX];
+#pragma unroll
+  for (int o = 0; o < NO_MAX; ++o) acc[o] = 0.0f;
+  for (int k = lane8; k < K; k += 8) {
+    float x = X[(size_t)row * K + k];
+#pragma unroll
+    for (int o = 0; o < NO_MAX; ++o) if (o < NO) acc[o] += x * sw[o * K + k];
+  }
+#pragma unroll
+  for (int o = 0; o < NO_MAX; ++o) {
+    float v = acc[o];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    if (o < NO && lane8 == 0) Y[(size_t)row * NO + o] = v + b[o];
+  }
+}
+// backward of the thin head: Gprev[M,K] = (dY[M,NO] W[NO,K]) * ELU'(H[M,K]);  slabs: dW[NO,K] and db[NO] partials
+template <int NO_MAX>
+__global__ void k_thin_bwd(int M, int K, int NO, int rows_per_block, const float* __restrict__ dY, const float* __restrict__ H,
+                           const float* __restrict__ W, float* __restrict__ Gprev, float* __restrict__ slabsW, float* __restrict__ slabsB) {
+  int k = threadIdx.x;              // blockDim.x >= K
+  int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float w[NO_MAX], dw[NO_MAX], db[NO_MAX];
+#pragma unroll
+  for (int o = 0; o < NO_MAX; ++o) { w[o] = (o < NO && k < K) ? W[o * K + k] : 0.0f; dw[o] = 0.0f; db[o] = 0.0f; }
+  for (int r = r0; r < r1; ++r) {
+    float h = k < K ? H[(size_t)r * K + k] : 0.0f, g = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO_MAX; ++o) if (o < NO) { float d = dY[(size_t)r * NO + o]; g += d * w[o]; dw[o] += d * h; db[o] += d; }
+    if (k < K) Gprev[(size_t)r * K + k] = g * (h > 0.0f ? 1.0f : h + 1.0f);
+  }
+#pragma unroll
+  for (int o = 0; o < NO_MAX; ++o) if (o < NO) {
+    if (k < K) slabsW[((size_t)blockIdx.x * NO + o) * K + k] = dw[o];
+    if (k == 0) slabsB[(size_t)blockIdx.x * NO + o] = db[o];
+  }
+}
+
+// ------------------------------------------------------------------------------------- PPO loss (forward + gradient wrt heads)
+// Per sample: surrogate / clipped value / entropy losses and KL (rsl_rl PPO.update); writes dL/dmean, dL/dvalue
+// (already scaled by 1/B and the loss coefficients) and per-block partials: [0..A) dL/dstd, A: kl, A+1: value loss,
+// A+2: surrogate loss, A+3: entropy.
+__global__ void k_loss(int B, int A, float clip, float vcoef, float ecoef, int clipped_value,
+                       const float* __restrict__ mean, const float* __restrict__ value, const float* __restrict__ stdp,
+                       const float* __restrict__ act, const float* __restrict__ old_logp, const float* __restrict__ old_mu,
+                       const float* __restrict__ old_sigma, const float* __restrict__ adv, const float* __restrict__ ret,
+                       const float* __restrict__ old_val, float* __restrict__ dmean, float* __restrict__ dvalue,
+                       float* __restrict__ partial) {
+  __shared__ float sm[8];
+  float dstd[8], kl = 0.0f, vl = 0.0f, sl = 0.0f, en = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dstd[k] = 0.0f;
+  const float invB = 1.0f / (float)B;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+    float lp = 0.0f, kls = 0.0f, ens = 0.0f;
+    float dmu[8], dsg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < A) {
+      float mu = mean[(size_t)i * A + k], sg = stdp[k], a = act[(size_t)i * A + k];
+      float d = a - mu;
+      lp += -0.5f * (d * d) / (sg * sg) - logf(sg) - 0.91893853320467274178f;
+      dmu[k] = d / (sg * sg);
+      dsg[k] = (d * d) / (sg * sg * sg) - 1.0f / sg;
+      float om = old_mu[(size_t)i * A + k], os = old_sigma[(size_t)i * A + k];
+      kls += logf(sg / os + 1e-5f) + (os * os + (om - mu) * (om - mu)) / (2.0f * sg * sg) - 0.5f;
+      ens += 0.5f + 0.91893853320467274178f + logf(sg);
+    }
+    float ad = adv[i];
+    float ratio = expf(lp - old_logp[i]);
+    float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+    float g_lp = (s1 >= s2) ? (-ad * ratio) * invB : 0.0f;     // d(mean surrogate)/d(log_prob)
+    sl += fmaxf(s1, s2);
+    float v = value[i], r = ret[i], gv;
+    if (clipped_value) {
+      float ov = old_val[i];
+      float vc = ov + fminf(fmaxf(v - ov, -clip), clip);
+      float e1 = (v - r) * (v - r), e2 = (vc - r) * (vc - r);
+      bool inside = fabsf(v - ov) < clip;          // v_clipped == v: both branches identical
+      gv = (e1 >= e2 || inside) ? 2.0f * (v - r) : 0.0f;
+      vl += fmaxf(e1, e2);
+    } else { gv = 2.0f * (v - r); vl += (r - v) * (r - v); }
+    dvalue[i] = vcoef * gv * invB;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < A) {
+      dmean[(size_t)i * A + k] = g_lp * dmu[k];
+      dstd[k] += g_lp * dsg[k];
+    }
+    kl += kls; en += ens;
+  }
+  float* out = partial + (size_t)blockIdx.x * (A + 4);
+  for (int k = 0; k < A; ++k) { float s = block_sum(dstd[k], sm); if (threadIdx.x == 0) out[k] = s; }
+  float s;
+  s = block_sum(kl, sm); if (threadIdx.x == 0) out[A] = s;
+  s = block_sum(vl, sm); if (threadIdx.x == 0) out[A + 1] = s;
+  s = block_sum(sl, sm); if (threadIdx.x == 0) out[A + 2] = s;
+  s = block_sum(en, sm); if (threadIdx.x == 0) out[A + 3] = s;
+}
+// finish the loss reductions: dL/dstd (incl. the entropy bonus), KL sum + count for the adaptive LR
+__global__ void k_loss_finish(int nb, int A, int B, float ecoef, const float* __restrict__ partial, const float* __restrict__ stdp,
+                              float* __restrict__ dstd, float* __restrict__ grads_tail, float* __restrict__ scalars) {
+  int k = threadIdx.x;
+  if (k < A + 4) {
+    float s = 0.0f;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * (A + 4) + k];
+    if (k < A) dstd[k] = s - ecoef / stdp[k];
+    else if (k == A) { grads_tail[0] = s; grads_tail[1] = (float)B; }
+    else if (k == A + 1) scalars[SC_VLOSS] += s / (float)B;
+    else if (k == A + 2) scalars[SC_SLOSS] += s / (float)B;
+    else scalars[SC_ENTROPY] = s / (float)B;
+  }
+}
+
+// ------------------------------------------------------------------------------------- optimiser
+__global__ void k_sumsq1(size_t n, const float* __restrict__ g, float scale, float* __restrict__ partial) {
+  __shared__ float sm[8];
+  float q = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { float v = g[i] * scale; q += v * v; }
+  q = block_sum(q, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = q;
+}
+// single thread: adaptive-KL learning rate (rsl_rl PPO.update), clip coefficient, Adam step counter
+__global__ void k_prepare_step(int nb, const float* __restrict__ partial, const float* __restrict__ grads_tail, int adaptive,
+                               float desired_kl, float max_grad_norm, float* __restrict__ scalars) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float q = 0.0f;
+  for (int b = 0; b < nb; ++b) q += partial[b];
+  float norm = sqrtf(q);
+  scalars[SC_GNORM] = norm;
+  float coef = max_grad_norm / (norm + 1e-6f);
+  scalars[SC_CLIPCOEF] = coef < 1.0f ? coef : 1.0f;
+  float kl = grads_tail[0] / grads_tail[1];
+  scalars[SC_KL] = kl;
+  if (adaptive && desired_kl > 0.0f) {
+    float lr = scalars[SC_LR];
+    if (kl > desired_kl * 2.0f) lr = fmaxf(1e-5f, lr / 1.5f);
+    else if (kl < desired_kl / 2.0f && kl > 0.0f) lr = fminf(1e-2f, lr * 1.5f);
+    scalars[SC_LR] = lr;
+  }
+  scalars[SC_STEP] += 1.0f;
+  scalars[SC_NUPD] += 1.0f;
+}
+__global__ void k_adam(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       float gscale, float b1, float b2, float eps, const float* __restrict__ scalars) {
+  float lr = scalars[SC_LR], coef = scalars[SC_CLIPCOEF] * gscale, t = scalars[SC_STEP];
+  float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  float step = lr / bc1, ibc2s = 1.0f / sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * coef;
+    float mi = b1 * m[i] + (1.0f - b1) * gi;
+    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step * mi / (sqrtf(vi) * ibc2s + eps);
+  }
+}
+
+}  // namespace
+
+// ============================================================================================ host side
+struct PpoAlg {
+  PpoConfig cfg;
+  PpoBuffers b;
+  Net actor, critic;
+  size_t std_off = 0, nparams = 0;
+  int device = 0;
+  bool bound = false;
+  int batch = 0;           // minibatch rows
+  // workspace carve (floats)
+  size_t w_xa, w_xc, w_act, w_oldlogp, w_oldmu, w_oldsig, w_adv, w_ret, w_oldval;
+  size_t w_ha[PPO_MAX_LAYERS], w_hc[PPO_MAX_LAYERS];   // activations per layer output (last = head output)
+  size_t w_dmean, w_dvalue, w_g[2], w_slabs, w_partial, w_lastval, w_total;
+  int max_rows = 0, max_width = 0, splits = 0;
+};
+
+static void net_layout(Net& n, const int* dims, int nl, size_t& off) {
+  n.nl = nl;
+  for (int i = 0; i < nl; ++i) {
+    n.l[i].in = dims[i]; n.l[i].out = dims[i + 1];
+    n.l[i].w = off; off += (size_t)dims[i] * dims[i + 1];
+    n.l[i].b = off; off += dims[i + 1];
+  }
+}
+
+static int ppo_check_cfg(const PpoConfig* c) {
+  if (!c) { pf_set_error("ppo: null config"); return 1; }
+  if (c->n_actor_layers < 2 || c->n_actor_layers > PPO_MAX_LAYERS || c->n_critic_layers < 2 || c->n_critic_layers > PPO_MAX_LAYERS) {
+    pf_set_error("ppo: 1..3 hidden layers supported"); return 1;
+  }
+  if (c->num_actions < 1 || c->num_actions > 8) { pf_set_error("ppo: num_actions must be in 1..8"); return 1; }
+  if (c->actor_dims[0] != c->num_obs || c->critic_dims[0] != c->num_critic_obs || c->actor_dims[c->n_actor_layers] != c->num_actions ||
+      c->critic_dims[c->n_critic_layers] != 1) { pf_set_error("ppo: layer dims inconsistent with obs/action sizes"); return 1; }
+  if ((c->num_envs * c->num_steps) % c->num_mini_batches != 0) { pf_set_error("ppo: num_envs*num_steps must divide by num_mini_batches"); return 1; }
+  for (int i = 1; i < c->n_actor_layers; ++i) if (c->actor_dims[i] > 1024) { pf_set_error("ppo: hidden width > 1024"); return 1; }
+  for (int i = 1; i < c->n_critic_layers; ++i) if (c->critic_dims[i] > 1024) { pf_set_error("ppo: hidden width > 1024"); return 1; }
+  return 0;
+}
+
+static void ppo_plan(PpoAlg* a) {
+  const PpoConfig& c = a->cfg;
+  size_t off = 0;
+  net_layout(a->actor, c.actor_dims, c.n_actor_layers, off);
+  net_layout(a->critic, c.critic_dims, c.n_critic_layers, off);
+  a->std_off = off; off += c.num_actions;
+  a->nparams = off;
+  a->batch = c.num_envs * c.num_steps / c.num_mini_batches;
+  a->max_rows = a->batch > c.num_envs ? a->batch : c.num_envs;
+  int mw = 0; size_t maxw = 0;
+  for (int i = 0; i < a->actor.nl; ++i) { mw = std::max(mw, a->actor.l[i].out); maxw = std::max(maxw, (size_t)a->actor.l[i].in * a->actor.l[i].out); }
+  for (int i = 0; i < a->critic.nl; ++i) { mw = std::max(mw, a->critic.l[i].out); maxw = std::max(maxw, (size_t)a->critic.l[i].in * a->critic.l[i].out); }
+  a->max_width = mw;
+  a->splits = 48;
+  size_t R = a->max_rows, w = 0;
+  auto take = [&](size_t n) { size_t at = w; w += (n + 63) & ~(size_t)63; return at; };
+  a->w_xa = take(R * c.num_obs); a->w_xc = take(R * c.num_critic_obs); a->w_act = take(R * c.num_actions);
+  a->w_oldlogp = take(R); a->w_oldmu = take(R * c.num_actions); a->w_oldsig = take(R * c.num_actions);
+  a->w_adv = take(R); a->w_ret = take(R); a->w_oldval = take(R);
+  for (int i = 0; i < a->actor.nl; ++i) a->w_ha[i] = take(R * a->actor.l[i].out);
+  for (int i = 0; i < a->critic.nl; ++i) a->w_hc[i] = take(R * a->critic.l[i].out);
+  a->w_dmean = take(R * c.num_actions); a->w_dvalue = take(R);
+  a->w_g[0] = take(R * mw); a->w_g[1] = take(R * mw);
+  size_t thin_blocks = (R + 255) / 256;
+  a->w_slabs = take(std::max<size_t>((size_t)a->splits * maxw, thin_blocks * 8 * 1024) + thin_blocks * 8 + (size_t)RED_BLOCKS * mw);
+  a->w_partial = take((size_t)RED_BLOCKS * 16);
+  a->w_lastval = take(c.num_envs);
+  a->w_total = w;
+}
+
+// forward through one MLP: X[M, in0] -> activations; hidden layers on the MFMA GEMM (bias + ELU fused), head on the thin kernel
+static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, hipStream_t s) {
+  float* ws = a->b.d_workspace; const float* P = a->b.d_params;
+  const float* in = X;
+  for (int i = 0; i < n.nl; ++i) {
+    const Layer& L = n.l[i];
+    float* out = ws + w_h[i];
+    if (i == n.nl - 1) {
+      int threads = 256, rows_per_block = threads / 8;
+      hipLaunchKernelGGL((k_thin_fwd<8>), dim3((M + rows_per_block - 1) / rows_per_block), dim3(threads), sizeof(float) * L.out * L.in, s,
+                         M, L.in, L.out, in, P + L.w, P + L.b, out);
+    } else {
+      GemmArgs g{};
+      g.A = in; g.B = P + L.w; g.C = out; g.M = M; g.N = L.out; g.K = L.in; g.lda = L.in; g.ldb = L.in; g.ldc = L.out; g.bias = P + L.b;
+      if (M >= 8192 && L.out >= 128) pf_gemm_launch<128, 128, true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
+      else pf_gemm_launch<64, 64, true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
+    }
+    in = out;
+  }
+}
+
+// backward through one MLP given dHead[M, out_last]; writes weight/bias gradients into d_grads
+static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, const float* dHead, hipStream_t s) {
+  float* ws = a->b.d_workspace; const float* P = a->b.d_params; float* G = a->b.d_grads;
+  float* slabs = ws + a->w_slabs;
+  const int last = n.nl - 1;
+  // thin head: dZ_{last-1}, dW_last, db_last
+  float* gcur = ws + a->w_g[0];
+  float* gnext = ws + a->w_g[1];
+  {
+    const Layer& L = n.l[last];
+    int rows_per_block = 256, nblk = (M + rows_per_block - 1) / rows_per_block;
+    int threads = (L.in + 63) / 64 * 64;
+    float* slabsW = slabs; float* slabsB = slabs + (size_t)nblk * L.out * L.in;
+    hipLaunchKernelGGL((k_thin_bwd<8>), dim3(nblk), dim3(threads), 0, s, M, L.in, L.out, rows_per_block, dHead, ws + w_h[last - 1], P + L.w,
+                       gcur, slabsW, slabsB);
+    int nw = L.out * L.in;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, nblk, slabsW, G + L.w);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(1), dim3(64), 0, s, L.out, nblk, slabsB, G + L.b);
+  }
+  for (int i = last - 1; i >= 0; --i) {
+    const Layer& L = n.l[i];
+    const float* in = i == 0 ? X : ws + w_h[i - 1];
+    // dW_i = gcur[M, out]^T * in[M, in]   (split over rows, deterministic slab reduce)
+    {
+      GemmArgs g{};
+      g.A = gcur; g.B = in; g.C = slabs; g.M = L.out; g.N = L.in; g.K = M; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
+      int per = ((M + a->splits - 1) / a->splits + 31) / 32 * 32;
+      int S = (M + per - 1) / per;
+      g.k_per_split = per;
+      if (L.out >= 128 && L.in >= 128) pf_gemm_launch<128, 128, false, false, GEMM_EPI_NONE>(g, S, s);
+      else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE>(g, S, s);
+      int nw = L.out * L.in;
+      hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, S, slabs, G + L.w);
+    }
+    // db_i = column sums of gcur
+    {
+      float* cs = slabs + (size_t)a->splits * L.out * L.in;
+      int rpb = (M + RED_BLOCKS - 1) / RED_BLOCKS;
+      int nchunk = (M + rpb - 1) / rpb;
+      hipLaunchKernelGGL(k_colsum1, dim3((L.out + 63) / 64, nchunk), dim3(64), 0, s, M, L.out, L.out, rpb, gcur, cs);
+      hipLaunchKernelGGL(k_reduce_slabs, dim3((L.out + 255) / 256), dim3(256), 0, s, L.out, nchunk, cs, G + L.b);
+    }
+    if (i > 0) {
+      // dZ_{i-1} = (gcur[M,out] * W_i[out,in]) * ELU'(h_{i-1})
+      GemmArgs g{};
+      g.A = gcur; g.B = P + L.w; g.C = gnext; g.M = M; g.N = L.in; g.K = L.out; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
+      g.H = ws + w_h[i - 1]; g.ldh = L.in;
+      if (M >= 8192 && L.in >= 128) pf_gemm_launch<128, 128, true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
+      else pf_gemm_launch<64, 64, true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
+      std::swap(gcur, gnext);
+    }
+  }
+}
+
+extern "C" {
+
+int64_t ppo_num_params(const PpoConfig* cfg) {
+  if (ppo_check_cfg(cfg)) return -1;
+  PpoAlg a; a.cfg = *cfg; ppo_plan(&a);
+  return (int64_t)a.nparams;
+}
+int64_t ppo_workspace_floats(const PpoConfig* cfg) {
+  if (ppo_check_cfg(cfg)) return -1;
+  PpoAlg a; a.cfg = *cfg; ppo_plan(&a);
+  return (int64_t)a.w_total;
+}
+
+PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
+  if (ppo_check_cfg(cfg)) return nullptr;
+  PpoAlg* a = new PpoAlg();
+  a->cfg = *cfg; a->device = device;
+  ppo_plan(a);
+  return a;
+}
+void ppo_destroy(PpoAlg* a) { delete a; }
+
+int ppo_bind_buffers(PpoAlg* a, const PpoBuffers* b) {
+  if (!a || !b) { pf_set_error("ppo_bind_buffers: null argument"); return 1; }
+  const void* req[] = {b->d_params, b->d_grads, b->d_adam_m, b->d_adam_v, b->d_obs, b->d_critic_obs, b->d_actions, b->d_rewards, b->d_dones,
+                       b->d_values, b->d_returns, b->d_advantages, b->d_log_prob, b->d_mu, b->d_sigma, b->d_perm, b->d_workspace, b->d_scalars};
+  for (const void* p : req) if (!p) { pf_set_error("ppo_bind_buffers: a required buffer is NULL"); return 1; }
+  if (b->workspace_floats < (int64_t)a->w_total) { pf_set_error("ppo_bind_buffers: workspace too small (see ppo_workspace_floats)"); return 1; }
+  a->b = *b; a->bound = true;
+  return 0;
+}
+
+int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs, float* d_actions_out, int64_t sample_counter,
+            const float* d_inject_normal, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_act: buffers not bound"); return 1; }
+  const PpoConfig& c = a->cfg;
+  if (t < 0 || t >= c.num_steps) { pf_set_error("ppo_act: transition index out of range (rollout buffer overflow)"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  const int N = c.num_envs, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
+  float* ws = a->b.d_workspace;
+  mlp_forward(a, a->actor, d_obs, N, a->w_ha, s);
+  mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s);
+  size_t tn = (size_t)t * N;
+  hipLaunchKernelGGL(k_sample, dim3((N + 255) / 256), dim3(256), 0, s, N, A, O, P, d_obs, d_critic_obs, ws + a->w_ha[a->actor.nl - 1],
+                     ws + a->w_hc[a->critic.nl - 1], a->b.d_params + a->std_off, d_inject_normal, c.seed_lo, c.seed_hi, (uint32_t)sample_counter,
+                     0u, d_actions_out, a->b.d_obs + tn * O, a->b.d_critic_obs + tn * P, a->b.d_actions + tn * A, a->b.d_values + tn,
+                     a->b.d_log_prob + tn, a->b.d_mu + tn * A, a->b.d_sigma + tn * A);
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ppo_act_inference(PpoAlg* a, const float* d_obs, int32_t n, float* d_actions_out, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_act_inference: buffers not bound"); return 1; }
+  if (n < 1 || n > a->max_rows) { pf_set_error("ppo_act_inference: batch larger than the workspace"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  mlp_forward(a, a->actor, d_obs, n, a->w_ha, s);
+  PPO_HIP_OK(hipMemcpyAsync(d_actions_out, a->b.d_workspace + a->w_ha[a->actor.nl - 1], sizeof(float) * n * a->cfg.num_actions,
+                            hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int ppo_process_env_step(PpoAlg* a, int32_t t, const float* d_rew, const uint8_t* d_dones, const uint8_t* d_time_outs, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_process_env_step: buffers not bound"); return 1; }
+  const PpoConfig& c = a->cfg;
+  if (t < 0 || t >= c.num_steps) { pf_set_error("ppo_process_env_step: transition index out of range"); return 1; }
+  size_t tn = (size_t)t * c.num_envs;
+  hipLaunchKernelGGL(k_process, dim3((c.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, c.num_envs, c.gamma, d_rew, d_dones,
+                     d_time_outs, a->b.d_values + tn, a->b.d_rewards + tn, a->b.d_dones + tn);
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ppo_compute_returns(PpoAlg* a, const float* d_last_critic_obs, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_compute_returns: buffers not bound"); return 1; }
+  const PpoConfig& c = a->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = a->b.d_workspace;
+  const int N = c.num_envs, T = c.num_steps;
+  mlp_forward(a, a->critic, d_last_critic_obs, N, a->w_hc, s);
+  PPO_HIP_OK(hipMemcpyAsync(ws + a->w_lastval, ws + a->w_hc[a->critic.nl - 1], sizeof(float) * N, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_gae, dim3((N + 255) / 256), dim3(256), 0, s, N, T, c.gamma, c.lam, ws + a->w_lastval, a->b.d_values, a->b.d_rewards,
+                     a->b.d_dones, a->b.d_returns, a->b.d_advantages);
+  size_t n = (size_t)N * T;
+  hipLaunchKernelGGL(k_moments1, dim3(RED_BLOCKS), dim3(256), 0, s, n, a->b.d_advantages, ws + a->w_partial);
+  hipLaunchKernelGGL(k_moments2, dim3(1), dim3(64), 0, s, RED_BLOCKS, n, ws + a->w_partial, a->b.d_scalars);
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ppo_normalize_advantages(PpoAlg* a, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_normalize_advantages: buffers not bound"); return 1; }
+  size_t n = (size_t)a->cfg.num_envs * a->cfg.num_steps;
+  hipLaunchKernelGGL(k_normalize, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, n, a->b.d_advantages, a->b.d_scalars);
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_minibatch_backward: buffers not bound"); return 1; }
+  const PpoConfig& c = a->cfg;
+  if (mb < 0 || mb >= c.num_mini_batches) { pf_set_error("ppo_minibatch_backward: minibatch index out of range"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = a->b.d_workspace;
+  const int B = a->batch, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
+  const int* perm = a->b.d_perm + (size_t)mb * B;
+  auto gather = [&](const float* src, size_t dst, int cols) {
+    size_t n = (size_t)B * cols;
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, cols, perm, src, ws + dst);
+  };
+  gather(a->b.d_obs, a->w_xa, O); gather(a->b.d_critic_obs, a->w_xc, P); gather(a->b.d_actions, a->w_act, A);
+  gather(a->b.d_log_prob, a->w_oldlogp, 1); gather(a->b.d_mu, a->w_oldmu, A); gather(a->b.d_sigma, a->w_oldsig, A);
+  gather(a->b.d_advantages, a->w_adv, 1); gather(a->b.d_returns, a->w_ret, 1); gather(a->b.d_values, a->w_oldval, 1);
+  mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s);
+  mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s);
+  const float* stdp = a->b.d_params + a->std_off;
+  hipLaunchKernelGGL(k_loss, dim3(RED_BLOCKS), dim3(256), 0, s, B, A, c.clip_param, c.value_loss_coef, c.entropy_coef, c.use_clipped_value_loss,
+                     ws + a->w_ha[a->actor.nl - 1], ws + a->w_hc[a->critic.nl - 1], stdp, ws + a->w_act, ws + a->w_oldlogp, ws + a->w_oldmu,
+                     ws + a->w_oldsig, ws + a->w_adv, ws + a->w_ret, ws + a->w_oldval, ws + a->w_dmean, ws + a->w_dvalue, ws + a->w_partial);
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, s, RED_BLOCKS, A, B, c.entropy_coef, ws + a->w_partial, stdp,
+                     a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
+  mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, ws + a->w_dmean, s);
+  mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, ws + a->w_dvalue, s);
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ppo_minibatch_apply(PpoAlg* a, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_minibatch_apply: buffers not bound"); return 1; }
+  const PpoConfig& c = a->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = a->b.d_workspace;
+  float gscale = 1.0f / (float)(c.world_size > 0 ? c.world_size : 1);
+  hipLaunchKernelGGL(k_sumsq1, dim3(RED_BLOCKS), dim3(256), 0, s, a->nparams, a->b.d_grads, gscale, ws + a->w_partial);
+  hipLaunchKernelGGL(k_prepare_step, dim3(1), dim3(64), 0, s, RED_BLOCKS, ws + a->w_partial, a->b.d_grads + a->nparams, c.adaptive_schedule,
+                     c.desired_kl, c.max_grad_norm, a->b.d_scalars);
+  hipLaunchKernelGGL(k_adam, dim3(RED_BLOCKS), dim3(256), 0, s, a->nparams, a->b.d_params, a->b.d_grads, a->b.d_adam_m, a->b.d_adam_v, gscale,
+                     c.adam_beta1, c.adam_beta2, c.adam_eps, a->b.d_scalars);
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

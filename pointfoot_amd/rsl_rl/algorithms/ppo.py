@@ -1,0 +1,207 @@
+"""PPO with the rsl_rl v1.0.2 surface (act / process_env_step / compute_returns / update), executed by the HIP kernels
+behind the ppo_* C ABI.  Multi-GPU: env-sharded data parallelism — every rank runs its own rollout and, per
+minibatch, the flat gradient (+ the KL sum in its tail) is all-reduced over RCCL before the fused clip + Adam step,
+so all ranks take identical parameter and learning-rate steps."""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from pointfoot_amd import _abi
+from pointfoot_amd.rsl_rl.storage import RolloutStorage
+
+SC_LR, SC_KL, SC_GNORM, SC_VLOSS, SC_SLOSS, SC_STEP = 0, 1, 2, 3, 4, 5
+SC_ADV_SUM = 10
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+class PPO:
+    def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
+                 schedule="fixed", desired_kl=0.01, device='cpu', seed=1):
+        if not str(device).startswith("cuda"):
+            raise RuntimeError(f"PPO (pointfoot_amd) runs on the MI355X HIP kernels only; got device={device!r}")
+        if actor_critic.activation_name != "elu":
+            raise NotImplementedError("the fused MLP kernels implement ELU (the activation both pointfoot tasks use)")
+        self.device = device
+        self.desired_kl = desired_kl
+        self.schedule = schedule
+        self.learning_rate = learning_rate
+        self.actor_critic = actor_critic
+        self.storage = None
+        self.transition = RolloutStorage.Transition()
+        self.clip_param = clip_param
+        self.num_learning_epochs = num_learning_epochs
+        self.num_mini_batches = num_mini_batches
+        self.value_loss_coef = value_loss_coef
+        self.entropy_coef = entropy_coef
+        self.gamma = gamma
+        self.lam = lam
+        self.max_grad_norm = max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.seed = seed
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self._lib = _abi.load()
+        self._h = None
+        self._sample_counter = 0
+        self.inject_normal = None      # tests: (N, A) standard-normal draws replacing Philox
+
+    # ------------------------------------------------------------------------------------------------ setup
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
+        dev, lib = self.device, self._lib
+        ac = self.actor_critic
+        self.storage = st = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, dev)
+        c = _abi.PpoConfig()
+        c.num_envs, c.num_steps = num_envs, num_transitions_per_env
+        c.num_obs, c.num_critic_obs, c.num_actions = ac.actor_dims[0], ac.critic_dims[0], ac.actor_dims[-1]
+        c.n_actor_layers, c.n_critic_layers = len(ac.actor_dims) - 1, len(ac.critic_dims) - 1
+        if max(c.n_actor_layers, c.n_critic_layers) > _abi.PPO_MAX_LAYERS:
+            raise ValueError("at most 3 hidden layers")
+        for i, d in enumerate(ac.actor_dims):
+            c.actor_dims[i] = d
+        for i, d in enumerate(ac.critic_dims):
+            c.critic_dims[i] = d
+        c.num_learning_epochs, c.num_mini_batches = self.num_learning_epochs, self.num_mini_batches
+        c.use_clipped_value_loss = int(self.use_clipped_value_loss)
+        c.adaptive_schedule = int(self.schedule == "adaptive")
+        c.clip_param, c.value_loss_coef, c.entropy_coef = self.clip_param, self.value_loss_coef, self.entropy_coef
+        c.gamma, c.lam, c.desired_kl = self.gamma, self.lam, (self.desired_kl if self.desired_kl is not None else 0.0)
+        c.max_grad_norm, c.learning_rate = self.max_grad_norm, self.learning_rate
+        c.adam_beta1, c.adam_beta2, c.adam_eps = 0.9, 0.999, 1e-8
+        c.world_size = self.world_size
+        c.seed_lo, c.seed_hi = (self.seed * 2654435761 + self.rank) & 0xFFFFFFFF, 0x85EBCA6B
+        self._cfg = c
+        P = lib.ppo_num_params(C.byref(c))
+        if P < 0:
+            raise RuntimeError("ppo: " + lib.pf_last_error().decode())
+        self.num_params = P
+        z = lambda n, dt=torch.float32: torch.zeros(n, device=dev, dtype=dt)
+        self.params = z(P)
+        ac.to(dev)
+        assert ac.flatten_into(self.params) == P
+        if self.world_size > 1:                       # identical initial policy on every rank
+            dist.broadcast(self.params, src=0)
+        self.grads = z(P + 4)                         # tail: [P] = KL sum, [P+1] = sample count
+        self.adam_m, self.adam_v = z(P), z(P)
+        self.scalars = z(16)
+        self.scalars[SC_LR] = self.learning_rate
+        ws = lib.ppo_workspace_floats(C.byref(c))
+        self.workspace = z(ws)
+        self.perm = z(num_envs * num_transitions_per_env, torch.int32)
+        self._h = lib.ppo_create(C.byref(c), torch.device(dev).index or 0)
+        if not self._h:
+            raise RuntimeError("ppo_create: " + lib.pf_last_error().decode())
+        b = _abi.PpoBuffers()
+        b.d_params, b.d_grads, b.d_adam_m, b.d_adam_v = _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v)
+        b.d_obs, b.d_critic_obs, b.d_actions = _ptr(st.observations), _ptr(st.privileged_observations), _ptr(st.actions)
+        b.d_rewards, b.d_dones, b.d_values = _ptr(st.rewards), _ptr(st.dones), _ptr(st.values)
+        b.d_returns, b.d_advantages, b.d_log_prob = _ptr(st.returns), _ptr(st.advantages), _ptr(st.actions_log_prob)
+        b.d_mu, b.d_sigma, b.d_perm = _ptr(st.mu), _ptr(st.sigma), _ptr(self.perm)
+        b.d_workspace, b.workspace_floats, b.d_scalars = _ptr(self.workspace), ws, _ptr(self.scalars)
+        self._bufs = b
+        _abi.check(lib.ppo_bind_buffers(self._h, C.byref(b)), lib)
+        self._actions = torch.zeros(num_envs, c.num_actions, device=dev)
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------------------------------------ rollout
+    def act(self, obs, critic_obs):
+        t = self.storage.next_slot()
+        obs = obs.contiguous()
+        critic_obs = critic_obs.contiguous()
+        self._sample_counter += 1
+        _abi.check(self._lib.ppo_act(self._h, t, obs.data_ptr(), critic_obs.data_ptr(), self._actions.data_ptr(),
+                                     self._sample_counter, _ptr(self.inject_normal), self._stream()), self._lib)
+        self.transition.actions = self._actions
+        return self._actions
+
+    def process_env_step(self, rewards, dones, infos):
+        t = self.storage.next_slot()
+        to = infos.get('time_outs', None) if isinstance(infos, dict) else None
+        _abi.check(self._lib.ppo_process_env_step(self._h, t, rewards.data_ptr(), dones.data_ptr(), _ptr(to), self._stream()), self._lib)
+        self.storage.step += 1
+        self.transition.clear()
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        lib = self._lib
+        _abi.check(lib.ppo_compute_returns(self._h, last_critic_obs.contiguous().data_ptr(), self._stream()), lib)
+        if self.world_size > 1:      # global advantage statistics: 3 scalars (sum, sumsq, count)
+            dist.all_reduce(self.scalars[SC_ADV_SUM:SC_ADV_SUM + 3])
+        _abi.check(lib.ppo_normalize_advantages(self._h, self._stream()), lib)
+
+    # ------------------------------------------------------------------------------------------------ update
+    def update(self):
+        lib, st = self._lib, self.storage
+        n = st.num_envs * st.num_transitions_per_env
+        # rsl_rl mini_batch_generator: one randperm per update, reused by every epoch
+        self.perm.copy_(torch.randperm(n, device=self.device).to(torch.int32))
+        self.scalars[SC_VLOSS:SC_SLOSS + 1] = 0.0
+        for _epoch in range(self.num_learning_epochs):
+            for mb in range(self.num_mini_batches):
+                _abi.check(lib.ppo_minibatch_backward(self._h, mb, self._stream()), lib)
+                if self.world_size > 1:
+                    dist.all_reduce(self.grads)          # RCCL over xGMI: 1.68 MB for pointfoot_rough
+                _abi.check(lib.ppo_minibatch_apply(self._h, self._stream()), lib)
+        num_updates = self.num_learning_epochs * self.num_mini_batches
+        st.clear()
+        # 0-d device tensors: no host sync here; the runner converts them when it logs
+        return self.scalars[SC_VLOSS] / num_updates, self.scalars[SC_SLOSS] / num_updates
+
+    @property
+    def current_learning_rate(self):
+        return self.scalars[SC_LR]
+
+    # ------------------------------------------------------------------------------------------------ checkpoints
+    def optimizer_state_dict(self):
+        """torch.optim.Adam-compatible layout, parameters in `actor_critic.parameters()` order (std first)."""
+        order = list(self.actor_critic.parameters())
+        offs, o = {}, 0
+        for p in self.actor_critic.kernel_order():
+            offs[id(p)] = (o, p.numel(), p.shape)
+            o += p.numel()
+        state = {}
+        for i, p in enumerate(order):
+            a, n, shp = offs[id(p)]
+            state[i] = {"step": self.scalars[SC_STEP].detach().cpu().clone(),
+                        "exp_avg": self.adam_m[a:a + n].view(shp).clone(), "exp_avg_sq": self.adam_v[a:a + n].view(shp).clone()}
+        group = {"lr": float(self.scalars[SC_LR].item()), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        order = list(self.actor_critic.parameters())
+        offs, o = {}, 0
+        for p in self.actor_critic.kernel_order():
+            offs[id(p)] = (o, p.numel())
+            o += p.numel()
+        for i, p in enumerate(order):
+            s = sd["state"].get(i)
+            if s is None:
+                continue
+            a, n = offs[id(p)]
+            self.adam_m[a:a + n].copy_(s["exp_avg"].reshape(-1))
+            self.adam_v[a:a + n].copy_(s["exp_avg_sq"].reshape(-1))
+            self.scalars[SC_STEP] = float(s["step"])
+        if sd.get("param_groups"):
+            self.scalars[SC_LR] = float(sd["param_groups"][0]["lr"])
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.ppo_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,186 @@
+"""OnPolicyRunner with the rsl_rl v1.0.2 surface used by the reference (task_registry.py:147-154, train.py:44,
+play.py:58-64): learn / save / load / get_inference_policy, checkpoint keys model_state_dict /
+optimizer_state_dict / iter / infos, `fps = T*N / (collection + learn)` as the headline metric.
+
+Differences for the MI355X hot path: the rollout loop never synchronises with the host — episode statistics are
+accumulated on the device and only read when an iteration is logged; under torch.distributed every rank runs its env
+shard and rank 0 logs / checkpoints."""
+import os
+import statistics
+import time
+from collections import deque
+
+import torch
+import torch.distributed as dist
+
+from pointfoot_amd.rsl_rl.algorithms import PPO
+from pointfoot_amd.rsl_rl.modules import ActorCritic
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg, log_dir=None, device='cpu'):
+        self.cfg = train_cfg["runner"]
+        self.alg_cfg = train_cfg["algorithm"]
+        self.policy_cfg = train_cfg["policy"]
+        self.device = device
+        self.env = env
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        num_critic_obs = self.env.num_privileged_obs if self.env.num_privileged_obs is not None else self.env.num_obs
+        if self.cfg["policy_class_name"] != "ActorCritic":
+            raise NotImplementedError(f"policy class {self.cfg['policy_class_name']} (only the feed-forward ActorCritic is on the hot path)")
+        if self.cfg["algorithm_class_name"] != "PPO":
+            raise NotImplementedError(f"algorithm {self.cfg['algorithm_class_name']}")
+        policy_kwargs = {k: v for k, v in self.policy_cfg.items() if k != "init_member_classes"}
+        actor_critic = ActorCritic(self.env.num_obs, num_critic_obs, self.env.num_actions, **policy_kwargs).to(self.device)
+        alg_kwargs = {k: v for k, v in self.alg_cfg.items() if k != "init_member_classes"}
+        self.alg = PPO(actor_critic, device=self.device, seed=int(train_cfg.get("seed", 1)), **alg_kwargs)
+        self.num_steps_per_env = self.cfg["num_steps_per_env"]
+        self.save_interval = self.cfg["save_interval"]
+        self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs], [self.env.num_privileged_obs],
+                              [self.env.num_actions])
+        self.log_dir = log_dir
+        self.writer = None
+        self.tot_timesteps = 0
+        self.tot_time = 0
+        self.current_learning_iteration = 0
+        self.log_interval = int(self.cfg.get("log_interval", 1))
+        N, dev = self.env.num_envs, self.device
+        self._cur_reward_sum = torch.zeros(N, dtype=torch.float, device=dev)
+        self._cur_episode_length = torch.zeros(N, dtype=torch.float, device=dev)
+        self._ep_stats = torch.zeros(3, dtype=torch.float, device=dev)       # sum return, sum length, count (since last log)
+        self.rewbuffer = deque(maxlen=100)
+        self.lenbuffer = deque(maxlen=100)
+        _, _ = self.env.reset()
+
+    # ------------------------------------------------------------------------------------------------ training
+    def rollout(self, obs, critic_obs):
+        """num_steps_per_env env steps + GAE; no host synchronisation inside."""
+        alg, env = self.alg, self.env
+        ep_infos = []
+        for _ in range(self.num_steps_per_env):
+            actions = alg.act(obs, critic_obs)
+            obs, privileged_obs, rewards, dones, infos = env.step(actions)
+            critic_obs = privileged_obs if privileged_obs is not None else obs
+            alg.process_env_step(rewards, dones, infos)
+            if self.log_dir is not None and 'episode' in infos:
+                ep_infos.append(infos['episode'])
+            # episode bookkeeping on the device
+            self._cur_reward_sum += rewards
+            self._cur_episode_length += 1
+            d = dones.to(torch.float)
+            self._ep_stats[0] += (self._cur_reward_sum * d).sum()
+            self._ep_stats[1] += (self._cur_episode_length * d).sum()
+            self._ep_stats[2] += d.sum()
+            self._cur_reward_sum *= (1.0 - d)
+            self._cur_episode_length *= (1.0 - d)
+        alg.compute_returns(critic_obs)
+        return obs, critic_obs, ep_infos
+
+    def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        if self.log_dir is not None and self.writer is None and self.rank == 0:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self.writer = SummaryWriter(log_dir=self.log_dir, flush_secs=10)
+            except Exception:
+                self.writer = None
+        if init_at_random_ep_len:
+            self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
+        obs = self.env.get_observations()
+        privileged_obs = self.env.get_privileged_observations()
+        critic_obs = privileged_obs if privileged_obs is not None else obs
+        obs, critic_obs = obs.to(self.device), critic_obs.to(self.device)
+        self.alg.actor_critic.train()
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        for it in range(self.current_learning_iteration, tot_iter):
+            start = time.time()
+            obs, critic_obs, ep_infos = self.rollout(obs, critic_obs)
+            torch.cuda.synchronize(self.device)
+            stop = time.time()
+            collection_time = stop - start
+            start = stop
+            mean_value_loss, mean_surrogate_loss = self.alg.update()
+            torch.cuda.synchronize(self.device)
+            stop = time.time()
+            learn_time = stop - start
+            if self.rank == 0 and (it % self.log_interval == 0):
+                self.log(locals())
+            if self.log_dir is not None and self.rank == 0 and it % self.save_interval == 0:
+                self.save(os.path.join(self.log_dir, 'model_{}.pt'.format(it)))
+            ep_infos.clear()
+        self.current_learning_iteration += num_learning_iterations
+        if self.log_dir is not None and self.rank == 0:
+            self.save(os.path.join(self.log_dir, 'model_{}.pt'.format(self.current_learning_iteration)))
+
+    def log(self, locs, width=80, pad=35):
+        n_total = self.num_steps_per_env * self.env.num_envs * self.world_size
+        self.tot_timesteps += n_total
+        self.tot_time += locs['collection_time'] + locs['learn_time']
+        iteration_time = locs['collection_time'] + locs['learn_time']
+        stats = self._ep_stats.tolist()
+        self._ep_stats.zero_()
+        if stats[2] > 0:
+            self.rewbuffer.append(stats[0] / stats[2])
+            self.lenbuffer.append(stats[1] / stats[2])
+        ep_string = ''
+        if locs['ep_infos']:
+            for key in locs['ep_infos'][0]:
+                vals = [ep[key] for ep in locs['ep_infos'] if key in ep]
+                value = float(torch.stack([torch.as_tensor(v, dtype=torch.float).reshape(()).to(self.device) for v in vals]).mean())
+                if self.writer:
+                    self.writer.add_scalar('Episode/' + key, value, locs['it'])
+                ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
+        mean_std = float(self.alg.actor_critic.std.mean())
+        fps = int(n_total / iteration_time)
+        vl, sl, lr = float(locs['mean_value_loss']), float(locs['mean_surrogate_loss']), float(self.alg.current_learning_rate)
+        if self.writer:
+            w = self.writer
+            w.add_scalar('Loss/value_function', vl, locs['it'])
+            w.add_scalar('Loss/surrogate', sl, locs['it'])
+            w.add_scalar('Loss/learning_rate', lr, locs['it'])
+            w.add_scalar('Policy/mean_noise_std', mean_std, locs['it'])
+            w.add_scalar('Perf/total_fps', fps, locs['it'])
+            w.add_scalar('Perf/collection time', locs['collection_time'], locs['it'])
+            w.add_scalar('Perf/learning_time', locs['learn_time'], locs['it'])
+            if len(self.rewbuffer) > 0:
+                w.add_scalar('Train/mean_reward', statistics.mean(self.rewbuffer), locs['it'])
+                w.add_scalar('Train/mean_episode_length', statistics.mean(self.lenbuffer), locs['it'])
+                w.add_scalar('Train/mean_reward/time', statistics.mean(self.rewbuffer), self.tot_time)
+                w.add_scalar('Train/mean_episode_length/time', statistics.mean(self.lenbuffer), self.tot_time)
+        head = f" \033[1m Learning iteration {locs['it']}/{self.current_learning_iteration + locs['num_learning_iterations']} \033[0m "
+        log_string = (f"""{'#' * width}\n"""
+                      f"""{head.center(width, ' ')}\n\n"""
+                      f"""{'Computation:':>{pad}} {fps:.0f} steps/s (collection: {locs['collection_time']:.3f}s, learning {locs['learn_time']:.3f}s)\n"""
+                      f"""{'Value function loss:':>{pad}} {vl:.4f}\n"""
+                      f"""{'Surrogate loss:':>{pad}} {sl:.4f}\n"""
+                      f"""{'Mean action noise std:':>{pad}} {mean_std:.2f}\n""")
+        if len(self.rewbuffer) > 0:
+            log_string += (f"""{'Mean reward:':>{pad}} {statistics.mean(self.rewbuffer):.2f}\n"""
+                           f"""{'Mean episode length:':>{pad}} {statistics.mean(self.lenbuffer):.2f}\n""")
+        log_string += ep_string
+        log_string += (f"""{'-' * width}\n"""
+                       f"""{'Total timesteps:':>{pad}} {self.tot_timesteps}\n"""
+                       f"""{'Iteration time:':>{pad}} {iteration_time:.2f}s\n"""
+                       f"""{'Total time:':>{pad}} {self.tot_time:.2f}s\n""")
+        print(log_string)
+
+    # ------------------------------------------------------------------------------------------------ checkpoints
+    def save(self, path, infos=None):
+        torch.save({'model_state_dict': self.alg.actor_critic.state_dict(),
+                    'optimizer_state_dict': self.alg.optimizer_state_dict(),
+                    'iter': self.current_learning_iteration,
+                    'infos': infos}, path)
+
+    def load(self, path, load_optimizer=True):
+        loaded = torch.load(path, map_location=self.device, weights_only=False)
+        self.alg.actor_critic.load_state_dict(loaded['model_state_dict'])      # copies into the flat-buffer views
+        if load_optimizer:
+            self.alg.load_optimizer_state_dict(loaded['optimizer_state_dict'])
+        self.current_learning_iteration = loaded['iter']
+        return loaded['infos']
+
+    def get_inference_policy(self, device=None):
+        self.alg.actor_critic.eval()
+        if device is not None:
+            self.alg.actor_critic.to(device)
+        return self.alg.actor_critic.act_inference

@@ -1,0 +1,4 @@
+from .helpers import class_to_dict, get_load_path, get_args, export_policy_as_jit, set_seed, update_class_from_dict
+from .task_registry import task_registry
+from .math import *
+from .terrain import Terrain

@@ -1,0 +1,158 @@
+"""GPU parity tests of the HIP PPO kernels (through the ppo_* C ABI) against the plain-PyTorch fp32 restatement of
+rsl_rl's PPO in oracle/ppo_ref.py (autograd reference; rsl_rl itself is absent: parity unpinned)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import common
+
+sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+import ppo_ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+ALG = dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01, num_learning_epochs=5,
+           num_mini_batches=4, learning_rate=1e-3, schedule="adaptive", gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0)
+
+
+def make(N, T, O, P, A, hidden, seed=0):
+    from pointfoot_amd.rsl_rl.modules import ActorCritic
+    from pointfoot_amd.rsl_rl.algorithms import PPO
+    torch.manual_seed(seed)
+    ac = ActorCritic(O, P, A, hidden, hidden, "elu", 1.0)
+    alg = PPO(ac, device="cuda:0", **ALG)
+    alg.init_storage(N, T, [O], [P], [A])
+    ref = ppo_ref.RefActorCritic(O, P, A, hidden, hidden).to("cuda:0")
+    ref.load_flat(alg.params)
+    return alg, ref
+
+
+def fill_rollout(alg, ref, N, T, O, P, A, gen):
+    dev = "cuda:0"
+    R = lambda *s: torch.randn(*s, device=dev, generator=gen)
+    recs = []
+    for t in range(T):
+        obs, cobs, noise = R(N, O), R(N, P), R(N, A)
+        alg.inject_normal = noise
+        a = alg.act(obs, cobs).clone()
+        r = ppo_ref.act(ref, obs, cobs, noise)
+        torch.testing.assert_close(a, r["actions"], atol=2e-5, rtol=1e-5)
+        st = alg.storage
+        torch.testing.assert_close(st.values[t, :, 0], r["values"][:, 0], atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(st.actions_log_prob[t, :, 0], r["log_prob"], atol=1e-4, rtol=1e-5)
+        torch.testing.assert_close(st.mu[t], r["mu"], atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(st.observations[t], obs)
+        torch.testing.assert_close(st.privileged_observations[t], cobs)
+        rew = R(N)
+        dones = torch.rand(N, device=dev, generator=gen) < 0.1
+        tos = dones & (torch.rand(N, device=dev, generator=gen) < 0.5)
+        alg.process_env_step(rew, dones, {"time_outs": tos})
+        rr = ppo_ref.process_rewards(rew, r["values"], tos, ALG["gamma"])
+        torch.testing.assert_close(st.rewards[t, :, 0], rr, atol=1e-5, rtol=1e-5)
+        recs.append(dict(rewards=rr, dones=dones.float(), values=r["values"][:, 0]))
+    last = R(N, P)
+    alg.compute_returns(last)
+    with torch.no_grad():
+        lv = ref.critic(last)[:, 0]
+    V = torch.stack([x["values"] for x in recs]); Rw = torch.stack([x["rewards"] for x in recs]); D = torch.stack([x["dones"] for x in recs])
+    ret, adv, _ = ppo_ref.compute_returns(V, Rw, D, lv, ALG["gamma"], ALG["lam"])
+    torch.testing.assert_close(alg.storage.returns[:, :, 0], ret, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(alg.storage.advantages[:, :, 0], adv, atol=2e-4, rtol=1e-4)
+    return last
+
+
+def ref_store(alg):
+    st = alg.storage
+    f = lambda x: x.flatten(0, 1).clone()
+    return dict(obs=f(st.observations), critic_obs=f(st.privileged_observations), actions=f(st.actions),
+                values=f(st.values)[:, 0], returns=f(st.returns)[:, 0], advantages=f(st.advantages)[:, 0],
+                old_log_prob=f(st.actions_log_prob)[:, 0], old_mu=f(st.mu), old_sigma=f(st.sigma))
+
+
+@pytest.mark.parametrize("N,T,O,P,A,hidden", [(96, 8, 27, 27, 6, [128, 64, 32]), (160, 6, 27, 148, 6, [512, 256, 128])])
+def test_rollout_gae_and_full_update_match_autograd(N, T, O, P, A, hidden):
+    alg, ref = make(N, T, O, P, A, hidden)
+    gen = torch.Generator(device="cuda:0").manual_seed(1)
+    fill_rollout(alg, ref, N, T, O, P, A, gen)
+    store = ref_store(alg)
+    perm = torch.randperm(N * T, device="cuda:0", generator=gen)
+    # --- one minibatch: gradients
+    alg.perm.copy_(perm.to(torch.int32))
+    common._abi.check(alg._lib.ppo_minibatch_backward(alg._h, 1, alg._stream()))
+    B = N * T // 4
+    idx = perm[B:2 * B].long()
+    mb = {k: v[idx] for k, v in store.items()}
+    loss, kl, vl, sl = ppo_ref.minibatch_loss(ref, mb, ALG["clip_param"], ALG["value_loss_coef"], ALG["entropy_coef"])
+    ref.zero_grad()
+    loss.backward()
+    g_ref = ref.flat_grad()
+    g = alg.grads[:alg.num_params]
+    scale = g_ref.abs().max().item()
+    assert (g - g_ref).abs().max().item() <= 2e-4 * scale + 1e-7, ((g - g_ref).abs().max().item(), scale)
+    assert abs(alg.grads[alg.num_params].item() / alg.grads[alg.num_params + 1].item() - kl.item()) <= 1e-5 + 1e-3 * abs(kl.item())
+    # --- the whole update (5 epochs x 4 minibatches, adaptive LR, clip, Adam)
+    opt = torch.optim.Adam(ref.parameters(), lr=ALG["learning_rate"])
+    cfg = dict(ALG)
+    lr, mv, ms = ppo_ref.update(ref, opt, store, perm, cfg, ALG["learning_rate"])
+    orig = torch.randperm
+    torch.randperm = lambda n, **kw: perm
+    try:
+        v_loss, s_loss = alg.update()
+    finally:
+        torch.randperm = orig
+    torch.cuda.synchronize()
+    assert abs(alg.current_learning_rate.item() - lr) <= 1e-9 + 1e-6 * lr, (alg.current_learning_rate.item(), lr)
+    p_ref = ref.flat()
+    err = (alg.params - p_ref).abs().max().item()
+    assert err <= 3e-4, err
+    assert abs(v_loss.item() - mv) <= 1e-3 * max(1.0, abs(mv)) and abs(s_loss.item() - ms) <= 1e-3 * max(1.0, abs(ms))
+    # nn.Module views see the kernel's updates (flat-buffer aliasing)
+    torch.testing.assert_close(alg.actor_critic.actor[0].weight, ref.actor[0].weight, atol=3e-4, rtol=0)
+
+
+def test_full_size_minibatch_gradient():
+    """BASELINE shapes (4096 envs x 24 steps, 512/256/128, 148-dim critic): one minibatch forward/backward vs autograd."""
+    N, T, O, P, A, hidden = 4096, 24, 27, 148, 6, [512, 256, 128]
+    alg, ref = make(N, T, O, P, A, hidden)
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(3)
+    st = alg.storage
+    R = lambda *s: torch.randn(*s, device=dev, generator=gen)
+    st.observations.copy_(R(T, N, O)); st.privileged_observations.copy_(R(T, N, P))
+    with torch.no_grad():
+        mu = ref.actor(st.observations.flatten(0, 1)).view(T, N, A)
+        st.mu.copy_(mu + 0.05 * R(T, N, A)); st.sigma.fill_(1.0)
+        st.actions.copy_(mu + R(T, N, A))
+        st.values.copy_(ref.critic(st.privileged_observations.flatten(0, 1)).view(T, N, 1) + 0.1 * R(T, N, 1))
+        st.actions_log_prob.copy_((-0.5 * (st.actions - st.mu) ** 2 - 0.9189385).sum(-1, keepdim=True))
+    st.returns.copy_(R(T, N, 1)); st.advantages.copy_(R(T, N, 1))
+    perm = torch.randperm(N * T, device=dev, generator=gen)
+    alg.perm.copy_(perm.to(torch.int32))
+    common._abi.check(alg._lib.ppo_minibatch_backward(alg._h, 2, alg._stream()))
+    store = ref_store(alg)
+    B = N * T // 4
+    mb = {k: v[perm[2 * B:3 * B].long()] for k, v in store.items()}
+    loss, kl, _, _ = ppo_ref.minibatch_loss(ref, mb, ALG["clip_param"], ALG["value_loss_coef"], ALG["entropy_coef"])
+    ref.zero_grad(); loss.backward()
+    g_ref, g = ref.flat_grad(), alg.grads[:alg.num_params]
+    scale = g_ref.abs().max().item()
+    assert (g - g_ref).abs().max().item() <= 3e-4 * scale, ((g - g_ref).abs().max().item(), scale)
+    # determinism: a second launch gives bit-identical gradients (atomic-free reductions)
+    g1 = g.clone()
+    common._abi.check(alg._lib.ppo_minibatch_backward(alg._h, 2, alg._stream()))
+    assert torch.equal(g1, alg.grads[:alg.num_params])
+
+
+def test_gemm_shapes_against_torch():
+    """act_inference on odd batch sizes exercises the GEMM's M/N/K edge handling (K=27/148, M not a tile multiple)."""
+    alg, ref = make(200, 4, 27, 148, 6, [512, 256, 128])
+    for n in (1, 50, 199, 200):
+        x = torch.randn(n, 27, device="cuda:0")
+        out = torch.zeros(n, 6, device="cuda:0")
+        common._abi.check(alg._lib.ppo_act_inference(alg._h, x.data_ptr(), n, out.data_ptr(), alg._stream()))
+        with torch.no_grad():
+            torch.testing.assert_close(out, ref.actor(x), atol=2e-5, rtol=1e-5)
