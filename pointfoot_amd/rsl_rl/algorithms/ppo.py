@@ -8,6 +8,7 @@ import torch
 import torch.distributed as dist
 
 from pointfoot_amd import _abi
+from pointfoot_amd.rsl_rl import dp
 from pointfoot_amd.rsl_rl.storage import RolloutStorage
 
 SC_LR, SC_KL, SC_GNORM, SC_VLOSS, SC_SLOSS, SC_STEP = 0, 1, 2, 3, 4, 5
@@ -83,8 +84,7 @@ class PPO:
         self.params = z(P)
         ac.to(dev)
         assert ac.flatten_into(self.params) == P
-        if self.world_size > 1:                       # identical initial policy on every rank
-            dist.broadcast(self.params, src=0)
+        dp.sync_params(self.params)                   # identical initial policy on every rank
         self.grads = z(P + 4)                         # tail: [P] = KL sum, [P+1] = sample count
         self.adam_m, self.adam_v = z(P), z(P)
         self.scalars = z(16)
@@ -137,8 +137,7 @@ class PPO:
     def compute_returns(self, last_critic_obs):
         lib = self._lib
         _abi.check(lib.ppo_compute_returns(self._h, last_critic_obs.contiguous().data_ptr(), self._stream()), lib)
-        if self.world_size > 1:      # global advantage statistics: 3 scalars (sum, sumsq, count)
-            dist.all_reduce(self.scalars[SC_ADV_SUM:SC_ADV_SUM + 3])
+        dp.allreduce_adv_stats(self.scalars[SC_ADV_SUM:SC_ADV_SUM + 3])   # global advantage statistics
         _abi.check(lib.ppo_normalize_advantages(self._h, self._stream()), lib)
 
     # ------------------------------------------------------------------------------------------------ update
@@ -151,8 +150,7 @@ class PPO:
         for _epoch in range(self.num_learning_epochs):
             for mb in range(self.num_mini_batches):
                 _abi.check(lib.ppo_minibatch_backward(self._h, mb, self._stream()), lib)
-                if self.world_size > 1:
-                    dist.all_reduce(self.grads)          # RCCL over xGMI: 1.68 MB for pointfoot_rough
+                dp.allreduce_grads(self.grads)           # RCCL over xGMI: 1.68 MB for pointfoot_rough
                 _abi.check(lib.ppo_minibatch_apply(self._h, self._stream()), lib)
         num_updates = self.num_learning_epochs * self.num_mini_batches
         st.clear()

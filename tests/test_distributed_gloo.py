@@ -1,0 +1,98 @@
+"""world_size-2 tests of the N>1 path on CPU (gloo): (1) env sharding — two ranks of N envs produce exactly the
+observations of one process with 2N envs (Philox streams and terrain types are keyed by the GLOBAL env index);
+(2) data-parallel update — all-reducing per-shard gradients (+ KL tail) through pointfoot_amd.rsl_rl.dp and applying
+clip + Adam gives the single-process result on the concatenated batch, with identical learning-rate decisions."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import common
+
+sys.path.insert(0, os.path.join(common.ROOT, "oracle"))
+
+
+def _env_shard_sim(n, base, n_global):
+    import synth
+    cfg = common.make_cfg("rough", n)
+    hf, to = synth.synth_heightfield(), synth.synth_terrain_origins().astype(np.float32)
+    sim = common.HostSim(cfg, n, hf=hf, terrain_origins=to, seed=5)
+    sim.c.env_index_base, sim.c.num_envs_global = base, n_global
+    rs = np.random.RandomState(11)
+    full = dict(root=rs.uniform(-1, 1, (n_global, 2)), q=rs.uniform(-0.1, 0.1, (n_global, 6)), lvl=rs.randint(0, 6, n_global))
+    g = np.arange(base, base + n)
+    sim.terrain_level[:] = full["lvl"][g]
+    sim.terrain_type[:] = g // max(n_global // 20, 1) % 20
+    sim.f("env_origin", 3)[:] = to[sim.terrain_level, sim.terrain_type]
+    sim.f("root", 13)[:, :3] = sim.f("env_origin", 3)
+    sim.f("root", 13)[:, :2] += full["root"][g]
+    sim.f("root", 13)[:, 2] += 0.75
+    sim.f("dof_pos", 6)[:] = full["q"][g]
+    sim.f("friction")[:] = 0.8
+    return sim, g
+
+
+def test_env_shards_equal_one_big_run():
+    n, W = 16, 2
+    big, _ = _env_shard_sim(n * W, 0, n * W)
+    shards = [_env_shard_sim(n, r * n, n * W) for r in range(W)]
+    rs = np.random.RandomState(2)
+    for t in range(6):
+        act = rs.normal(0, 0.6, (n * W, 6)).astype(np.float32)
+        big.step("emu", act, t + 1)
+        for sim, g in shards:
+            sim.step("emu", act[g], t + 1)
+            np.testing.assert_array_equal(sim.obs, big.obs[g])
+            np.testing.assert_array_equal(sim.priv, big.priv[g])
+            np.testing.assert_array_equal(sim.rew, big.rew[g])
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ppo_ref
+    from pointfoot_amd.rsl_rl import dp
+    torch.manual_seed(100 + rank)                      # ranks start from DIFFERENT weights ...
+    ac = ppo_ref.RefActorCritic(27, 27, 6, [32, 16], [32, 16])
+    flat = ac.flat().clone()
+    dp.sync_params(flat)                               # ... and are made identical by the rank-0 broadcast
+    ac.load_flat(flat)
+    g = torch.Generator().manual_seed(7)               # same global batch everywhere, each rank takes its slice
+    B = 64
+    data = dict(obs=torch.randn(B * world, 27, generator=g), critic_obs=torch.randn(B * world, 27, generator=g),
+                actions=torch.randn(B * world, 6, generator=g), values=torch.randn(B * world, generator=g),
+                returns=torch.randn(B * world, generator=g), advantages=torch.randn(B * world, generator=g),
+                old_log_prob=-8 + torch.randn(B * world, generator=g) * 0.1, old_mu=torch.randn(B * world, 6, generator=g) * 0.1,
+                old_sigma=torch.ones(B * world, 6))
+    mb = {k: v[rank * B:(rank + 1) * B] for k, v in data.items()}
+    loss, kl, _, _ = ppo_ref.minibatch_loss(ac, mb, 0.2, 1.0, 0.01)
+    ac.zero_grad(); loss.backward()
+    grads = torch.cat([ac.flat_grad(), torch.tensor([kl.item() * B, float(B), 0.0, 0.0])])     # tail: KL sum, count
+    dp.allreduce_grads(grads)
+    P = grads.numel() - 4
+    gmean = grads[:P] / world                          # what ppo_minibatch_apply does (gscale = 1/world_size)
+    kl_global = (grads[P] / grads[P + 1]).item()
+    stats = torch.tensor([float(rank + 1), 2.0, 3.0]); dp.allreduce_adv_stats(stats)
+    if rank == 0:
+        torch.save(dict(flat=flat, gmean=gmean, kl=kl_global, stats=stats, data=data), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_matches_single_process(tmp_path):
+    import ppo_ref
+    out = str(tmp_path / "dp.pt")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    ac = ppo_ref.RefActorCritic(27, 27, 6, [32, 16], [32, 16])
+    ac.load_flat(r["flat"])
+    loss, kl, _, _ = ppo_ref.minibatch_loss(ac, r["data"], 0.2, 1.0, 0.01)      # the concatenated global batch
+    ac.zero_grad(); loss.backward()
+    torch.testing.assert_close(r["gmean"], ac.flat_grad(), atol=1e-6, rtol=1e-4)
+    assert abs(r["kl"] - kl.item()) < 1e-6
+    torch.testing.assert_close(r["stats"], torch.tensor([3.0, 4.0, 6.0]))

@@ -1,0 +1,106 @@
+"""CPU tests of the host side: C-ABI export surface, config/registry/CLI mirrors, terrain generator."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import common
+from pointfoot_amd import _abi
+
+
+def test_library_exports_every_declared_symbol_and_abi_sizes_match():
+    hdr = open(os.path.join(common.ROOT, "include", "pointfoot_hip.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b((?:pf|ppo)_[a-z_0-9]+)\s*\(", body))
+    assert declared == set(_abi.EXPORTED_SYMBOLS), declared ^ set(_abi.EXPORTED_SYMBOLS)
+    lib = C.CDLL(_abi.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), f"libpointfoot_hip.so does not export {name}"
+    _abi.load()      # checks pf_abi_sizes against the ctypes mirror
+
+
+def test_pf_layout_host_only_and_error_reporting():
+    lib = _abi.load()
+    sim = common.HostSim(common.make_cfg("rough", 8), 8, hf=np.zeros((1300, 2100), np.int16),
+                         terrain_origins=np.zeros((10, 20, 3), np.float32))
+    L = _abi.PfLayout()
+    assert lib.pf_layout(C.byref(sim.model), C.byref(sim.c), C.byref(L)) == 0
+    assert bytes(L) == bytes(sim.L) and L.rec_floats % 16 == 0 and L.rand_floats >= 27 + 121 + 18
+    assert lib.pf_layout(None, None, None) != 0 and b"null" in lib.pf_last_error()
+    bad = _abi.PfModel.from_buffer_copy(bytes(sim.model)); bad.nb = 7
+    assert not lib.pf_create(C.byref(bad), C.byref(sim.c), 0)
+    assert b"kernel instance" in lib.pf_last_error()
+
+
+def test_registry_cli_and_config_mirrors(tmp_path):
+    from pointfoot_amd.envs import task_registry, PointFoot, PointFootRoughCfg
+    from pointfoot_amd.utils.helpers import get_args, class_to_dict, update_cfg_from_args, get_load_path, parse_sim_params
+    assert set(task_registry.task_classes) == {"pointfoot_rough", "pointfoot_flat"}
+    with pytest.raises(ValueError, match="was not registered"):
+        task_registry.make_env("anymal_c_rough", args=get_args([]))
+    env_cfg, train_cfg = task_registry.get_cfgs("pointfoot_rough")
+    assert env_cfg.seed == train_cfg.seed == 1 and isinstance(env_cfg, PointFootRoughCfg)
+    d = class_to_dict(train_cfg)
+    assert list(d["algorithm"].keys()) == sorted(d["algorithm"].keys()) and "init_member_classes" in d
+    assert d["policy"]["actor_hidden_dims"] == [512, 256, 128] and d["runner"]["num_steps_per_env"] == 24
+    a = get_args([])
+    assert a.task == "pointfoot_rough" and a.sim_device == "cuda:0" and a.rl_device == "cuda:0" and a.physics_engine == 1
+    a = get_args(["--task", "pointfoot_flat", "--num_envs", "64", "--seed", "7", "--max_iterations", "3", "--headless", "--resume",
+                  "--sim_device", "cpu"])
+    assert a.sim_device == "cpu" and not a.use_gpu_pipeline and not a.use_gpu
+    import copy
+    e2, t2 = update_cfg_from_args(copy.deepcopy(env_cfg), copy.deepcopy(train_cfg), a)
+    assert e2.env.num_envs == 64 and t2.seed == 7 and t2.runner.max_iterations == 3 and t2.runner.resume
+    sp = parse_sim_params(a, {"sim": class_to_dict(env_cfg.sim)})
+    assert sp.dt == 0.005 and sp.physx.num_position_iterations == 4 and sp.use_gpu_pipeline is False
+    # get_load_path: last run lexicographically, highest model number (helpers.py:103-125)
+    for run, models in (("Jan01_00-00-00_", ["model_0.pt", "model_50.pt", "model_100.pt"]), ("Jan02_00-00-00_", ["model_0.pt", "model_9.pt"])):
+        os.makedirs(tmp_path / run)
+        for m in models:
+            (tmp_path / run / m).write_bytes(b"")
+    os.makedirs(tmp_path / "exported")
+    assert get_load_path(str(tmp_path)).endswith(os.path.join("Jan02_00-00-00_", "model_9.pt"))
+    assert get_load_path(str(tmp_path), load_run="Jan01_00-00-00_").endswith("model_100.pt")
+    assert get_load_path(str(tmp_path), checkpoint=50).endswith(os.path.join("Jan02_00-00-00_", "model_50.pt"))
+    with pytest.raises(ValueError, match="No runs"):
+        get_load_path(str(tmp_path / "nope"))
+    # the env refuses to run without the HIP device instead of silently falling back
+    with pytest.raises(RuntimeError, match="HIP kernel only|no GPU"):
+        PointFoot(PointFootRoughCfg(), sp, 1, "cpu", True)
+
+
+def test_terrain_generator_layout_and_origins():
+    from pointfoot_amd.utils.terrain import Terrain
+    from pointfoot_amd.envs import PointFootRoughCfg
+    cfg = PointFootRoughCfg()
+    np.random.seed(1)
+    t = Terrain(cfg.terrain, 4096)
+    assert t.height_field_raw.shape == (1300, 2100) and t.height_field_raw.dtype == np.int16
+    assert t.env_origins.shape == (10, 20, 3)
+    np.testing.assert_allclose(t.env_origins[3, 5, :2], [3.5 * 8, 5.5 * 8])
+    hf = t.height_field_raw
+    assert (hf[:250] == 0).all() and (hf[:, :250] == 0).all() and (hf[-250:] == 0).all()      # flat 25 m border
+    tile = lambda i, j: hf[250 + 80 * i:250 + 80 * (i + 1), 250 + 80 * j:250 + 80 * (j + 1)]
+    assert tile(9, 0).min() < 0 and tile(9, 1).max() > 0               # col 0: downward pyramid, col 1: upward
+    assert tile(0, 0).min() == 0 and tile(0, 0).max() == 0             # difficulty 0 slope is flat
+    st = tile(9, 12)                                                   # stairs up, level 9: step 0.05 + 0.18*0.9
+    step = int((0.05 + 0.18 * 0.9) / 0.005)
+    assert set(np.unique(st)) <= {k * step for k in range(0, 20)} and st.max() >= 5 * step
+    assert tile(9, 5).min() < 0 and tile(9, 5).max() == 0 or tile(9, 5).min() < 0          # stairs down
+    assert abs(t.env_origins[9, 12, 2] - st[30:50, 30:50].max() * 0.005) < 1e-9
+    np.random.seed(1)
+    t2 = Terrain(PointFootRoughCfg().terrain, 4096)
+    assert (t2.height_field_raw == hf).all()                            # numpy-seeded, reproducible
+    cfg_plane = PointFootRoughCfg()
+    cfg_plane.terrain.mesh_type = "plane"
+    assert not hasattr(Terrain(cfg_plane.terrain, 8), "height_field_raw")
+
+
+def test_legged_robot_cfg_defaults_kept():
+    from pointfoot_amd.envs import LeggedRobotCfg, LeggedRobotCfgPPO
+    c, p = LeggedRobotCfg(), LeggedRobotCfgPPO()
+    assert c.env.num_envs == 4096 and c.env.num_observations == 235 and len(c.terrain.measured_points_x) == 17
+    assert c.rewards.only_positive_rewards and c.domain_rand.push_interval_s == 15 and c.sim.physx.solver_type == 1
+    assert p.algorithm.num_learning_epochs == 5 and p.runner.max_iterations == 1500 and p.policy.activation == "elu"
