@@ -213,6 +213,8 @@ int pf_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out);
 PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device);
 void pf_destroy(PfEnv* env);
 int pf_bind_buffers(PfEnv* env, const PfBuffers* bufs);
+/* re-point d_reset_stats (host-only; lets the caller rotate per-step statistics slots without copies) */
+int pf_set_reset_stats(PfEnv* env, float* d_reset_stats);
 /* replaces: gymapi tensors + update hooks; re-uploads config (e.g. after update_cmd / cfg edits) */
 int pf_update_config(PfEnv* env, const PfConfig* cfg);
 
@@ -270,6 +272,9 @@ typedef struct PpoBuffers {
   int32_t* d_perm;     /* [T*N] minibatch permutation (randperm), written by the host */
   float* d_workspace;  /* activations / gradients scratch */
   int64_t workspace_floats;
+  float* d_ep_return;  /* [N] running undiscounted return of the current episode (runner statistics), or NULL */
+  float* d_ep_length;  /* [N] running length of the current episode, or NULL */
+  float* d_ep_stats;   /* [4]: sum of finished-episode returns, sum of their lengths, count (since the host last zeroed it) */
   float* d_scalars;    /* [16]: 0 lr, 1 mean_kl, 2 grad_norm, 3 value_loss_sum, 4 surrogate_loss_sum,
                           5 adam_step, 6 adv_mean, 7 adv_std, 8 kl_sum_local, 9 n_updates */
 } PpoBuffers;

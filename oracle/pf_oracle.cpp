@@ -163,7 +163,7 @@ template <typename R> inline Sp6<R> spI_mul(const SpI<R>& I, const Sp6<R>& v) {
   return {symmul(I.I, v.a) + cross(I.h, v.l), I.m * v.l - cross(I.h, v.a)};
 }
 
-const int MAXC = 8;                              // contacts kept per robot (first active in sphere order)
+const int MAXC = 6;                              // contacts kept per robot (first active in sphere order)
 const int MAXROWS = 3 * MAXC + PF_MAX_DOF;
 const int NVMAX = 6 + PF_MAX_DOF;
 

@@ -118,7 +118,7 @@ class PpoBuffers(C.Structure):
     _fields_ = [(n, vp) for n in (
         "d_params", "d_grads", "d_adam_m", "d_adam_v", "d_obs", "d_critic_obs", "d_actions", "d_rewards", "d_dones",
         "d_values", "d_returns", "d_advantages", "d_log_prob", "d_mu", "d_sigma", "d_perm", "d_workspace")] + [
-        ("workspace_floats", C.c_int64), ("d_scalars", vp)]
+        ("workspace_floats", C.c_int64), ("d_ep_return", vp), ("d_ep_length", vp), ("d_ep_stats", vp), ("d_scalars", vp)]
 
 
 _LIB = None
@@ -154,6 +154,8 @@ def load():
     lib.pf_destroy.argtypes = [vp]
     lib.pf_bind_buffers.argtypes = [vp, C.POINTER(PfBuffers)]
     lib.pf_update_config.argtypes = [vp, C.POINTER(PfConfig)]
+    lib.pf_set_reset_stats.argtypes = [vp, vp]
+    lib.pf_set_reset_stats.restype = i32
     lib.pf_step.argtypes = [vp, vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_reset_all.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_compute_observations.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
@@ -192,7 +194,7 @@ def check(rc, lib=None):
 
 
 EXPORTED_SYMBOLS = [
-    "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers",
+    "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers", "pf_set_reset_stats",
     "pf_update_config", "pf_step", "pf_reset_all", "pf_compute_observations",
     "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_workspace_floats", "ppo_act",
     "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",

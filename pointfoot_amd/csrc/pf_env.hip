@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -24,10 +25,13 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // One wavefront (= one 64-thread workgroup) per robot.  LDS per workgroup is sizeof(Shared); the
 // grid is num_envs workgroups, dealt round-robin over the 8 XCDs by the dispatcher; every env only
 // touches its own record, so no inter-workgroup ordering is needed.
-template <int NB, int ND, int NF>
-__global__ __launch_bounds__(64) void pf_step_kernel(PfStepArgs g) {
+// model / cfg are separate __restrict__ const kernel arguments so the compiler can prove they are invariant and
+// read them with scalar loads (s_load) into SGPRs instead of holding hundreds of config values in VGPRs.
+template <int NB, int ND, int NF, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void pf_step_kernel(const PfModel* __restrict__ model, const PfConfig* __restrict__ cfg, PfStepArgs g) {
   using K = PfKernel<NB, ND, NF>;
   __shared__ typename K::Shared sh;
+  g.model = model; g.cfg = cfg;
   K::run(sh, g, (int)blockIdx.x);
 }
 
@@ -64,7 +68,7 @@ static int pf_validate(const PfModel* m, const PfConfig* c) {
     pf_set_error("pf_create: no kernel instance for this model (built: 9 bodies / 6 dofs / 2 feet)");
     return 1;
   }
-  if (m->nsph > PF_MAX_SPHERES || c->num_obs > PF_MAX_OBS || c->num_height_points > PF_MAX_HPTS ||
+  if (m->nsph > PF_KSPH || c->num_obs > PF_MAX_OBS || c->num_height_points > PF_MAX_HPTS ||
       c->num_rewards >= PF_MAX_REWARDS || c->num_actions != m->nd || c->num_obs != 9 + 3 * m->nd) {
     pf_set_error("pf_create: configuration outside the compiled limits");
     return 1;
@@ -81,6 +85,7 @@ PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device) {
   e->model = *model; e->cfg = *cfg; e->device = device;
   pf_compute_layout(model, cfg, &e->layout);
   if (e->layout.rec_floats > PF_REC_MAX) { pf_set_error("pf_create: state record exceeds PF_REC_MAX"); delete e; return nullptr; }
+  if (!PfKernel<9, 6, 2>::layout_matches(e->layout)) { pf_set_error("pf_create: record layout differs from the kernel's compile-time layout"); delete e; return nullptr; }
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&e->d_model, sizeof(PfModel)) != hipSuccess ||
       hipMalloc(&e->d_cfg, sizeof(PfConfig)) != hipSuccess ||
       hipMemcpy(e->d_model, model, sizeof(PfModel), hipMemcpyHostToDevice) != hipSuccess ||
@@ -116,6 +121,12 @@ int pf_bind_buffers(PfEnv* e, const PfBuffers* b) {
   return 0;
 }
 
+int pf_set_reset_stats(PfEnv* e, float* d_reset_stats) {
+  if (!e || !e->bound) { pf_set_error("pf_set_reset_stats: buffers not bound"); return 1; }
+  e->bufs.d_reset_stats = d_reset_stats;
+  return 0;
+}
+
 int pf_update_config(PfEnv* e, const PfConfig* cfg) {
   if (!e || !cfg) { pf_set_error("pf_update_config: null argument"); return 1; }
   if (pf_validate(&e->model, cfg)) return 1;
@@ -140,7 +151,12 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   g.actions = d_actions; g.step_counter = step_counter; g.mode = mode;
   hipStream_t s = (hipStream_t)stream;
   if (e->bufs.d_reset_stats && mode != 2) PF_HIP_OK(hipMemsetAsync(e->bufs.d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS, s));
-  hipLaunchKernelGGL((pf_step_kernel<9, 6, 2>), dim3(e->cfg.num_envs), dim3(64), 0, s, g);
+  // PF_STEP_WAVES selects the register budget variant (waves per SIMD the kernel is compiled for)
+  static const int variant = [] { const char* v = getenv("PF_STEP_WAVES"); return v ? atoi(v) : 4; }();
+  dim3 grid(e->cfg.num_envs), block(64);
+  if (variant == 4) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 4>), grid, block, 0, s, e->d_model, e->d_cfg, g);
+  else if (variant == 3) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 3>), grid, block, 0, s, e->d_model, e->d_cfg, g);
+  else hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 2>), grid, block, 0, s, e->d_model, e->d_cfg, g);
   PF_HIP_OK(hipGetLastError());
   return 0;
 }

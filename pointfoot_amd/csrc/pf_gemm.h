@@ -31,7 +31,7 @@ struct GemmArgs {
 __device__ __forceinline__ float pf_elu(float x) { return x > 0.0f ? x : (__expf(x) - 1.0f); }
 
 // A_KC: A stored [M][K] (k contiguous) else [K][M] (m contiguous).  B_KC: B stored [N][K] else [K][N].
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
 __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
   constexpr int BK = 32;
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
   if (g.k_per_split > 0) {
     k_begin = blockIdx.z * g.k_per_split;
     k_end = min(g.K, k_begin + g.k_per_split);
-    Cout += (size_t)blockIdx.z * g.M * g.ldc;
+    Cout += (size_t)blockIdx.z * ((size_t)g.M * g.ldc + (COLSUM ? g.M : 0));
   }
   constexpr int A_V4 = BM * BK / 4 / 256, B_V4 = BN * BK / 4 / 256;   // float4 chunks per thread
   float4 ra[A_V4], rb[B_V4];
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  float csum = 0.0f;   // COLSUM: sum over the reduction rows of A[:, m0 + tid] (bias gradient), blocks with blockIdx.x == 0
   const int arow = wr * (BM / 2) + (lane & 31), bcol = wc * (BN / 2) + (lane & 31), kh = lane >> 5;
   fetch(k_begin);
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
@@ -122,6 +123,10 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
     stage();
     __syncthreads();
     if (k0 + BK < k_end) fetch(k0 + BK);
+    if (COLSUM && blockIdx.x == 0 && tid < BM) {
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDA_S + tid];
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float a[TM], b[TN];
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
+  if (COLSUM && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) Cout[(size_t)g.M * g.ldc + m0 + tid] = csum;
   // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -155,8 +161,32 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
 static inline void pf_gemm_launch(const GemmArgs& g, int splits, hipStream_t s) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits > 0 ? splits : 1);
-  hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI>), grid, dim3(256), 0, s, g);
+  hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM>), grid, dim3(256), 0, s, g);
+}
+
+// Tile choice: the fp32 MFMA loop is matrix-pipe bound, so what matters is (a) per-tile efficiency (bigger tiles reuse
+// fragments more) and (b) how evenly the grid fills the 256 CUs (a 384-block grid costs as much as a 512-block one).
+static inline int pf_pick_tile(int M, int N, int splits) {
+  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+  const float eff[3] = {1.0f, 0.92f, 0.78f};
+  int best = 2; float best_score = -1.0f;
+  for (int i = 0; i < 3; ++i) {
+    long blocks = (long)((M + bm[i] - 1) / bm[i]) * ((N + bn[i] - 1) / bn[i]) * (splits > 0 ? splits : 1);
+    long rounds = (blocks + 255) / 256;
+    float useful = (float)M * (float)N / ((float)((M + bm[i] - 1) / bm[i]) * bm[i] * (float)((N + bn[i] - 1) / bn[i]) * bn[i]);
+    float score = eff[i] * useful * (float)blocks / (float)(rounds * 256);
+    if (score > best_score) { best_score = score; best = i; }
+  }
+  return best;
+}
+template <bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
+static inline void pf_gemm_auto(const GemmArgs& g, int splits, hipStream_t s) {
+  switch (pf_pick_tile(g.M, g.N, splits)) {
+    case 0: pf_gemm_launch<128, 128, A_KC, B_KC, EPI, COLSUM>(g, splits, s); break;
+    case 1: pf_gemm_launch<128, 64, A_KC, B_KC, EPI, COLSUM>(g, splits, s); break;
+    default: pf_gemm_launch<64, 64, A_KC, B_KC, EPI, COLSUM>(g, splits, s); break;
+  }
 }

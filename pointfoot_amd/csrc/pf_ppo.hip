@@ -59,6 +59,9 @@ __global__ void k_sample(int N, int A, int O, int P, const float* __restrict__ o
                          float* __restrict__ s_act, float* __restrict__ s_val, float* __restrict__ s_logp,
                          float* __restrict__ s_mu, float* __restrict__ s_sigma) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // transition copy (coalesced grid-stride), then one thread per env for the sample
+  for (size_t j = i; j < (size_t)N * O; j += (size_t)gridDim.x * blockDim.x) s_obs[j] = obs[j];
+  for (size_t j = i; j < (size_t)N * P; j += (size_t)gridDim.x * blockDim.x) s_cobs[j] = cobs[j];
   if (i >= N) return;
   float lp = 0.0f;
   for (int k = 0; k < A; ++k) {
@@ -79,19 +82,23 @@ __global__ void k_sample(int N, int A, int O, int P, const float* __restrict__ o
     s_act[(size_t)i * A + k] = a; s_mu[(size_t)i * A + k] = mu; s_sigma[(size_t)i * A + k] = sg;
   }
   s_val[i] = value[i]; s_logp[i] = lp;
-  for (int k = 0; k < O; ++k) s_obs[(size_t)i * O + k] = obs[(size_t)i * O + k];
-  for (int k = 0; k < P; ++k) s_cobs[(size_t)i * P + k] = cobs[(size_t)i * P + k];
 }
 
 // PPO.process_env_step: bootstrap on time-outs, store reward / done
 __global__ void k_process(int N, float gamma, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
                           const uint8_t* __restrict__ time_outs, const float* __restrict__ s_val, float* __restrict__ s_rew,
-                          float* __restrict__ s_done) {
+                          float* __restrict__ s_done, float* __restrict__ ep_ret, float* __restrict__ ep_len, float* __restrict__ ep_stats) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   float r = rew[i];
+  bool done = dones[i] != 0;
+  if (ep_ret) {     // OnPolicyRunner bookkeeping (cur_reward_sum / cur_episode_length / rewbuffer), kept on the device
+    float cr = ep_ret[i] + r, cl = ep_len[i] + 1.0f;
+    if (done) { atomicAdd(ep_stats, cr); atomicAdd(ep_stats + 1, cl); atomicAdd(ep_stats + 2, 1.0f); cr = 0.0f; cl = 0.0f; }
+    ep_ret[i] = cr; ep_len[i] = cl;
+  }
   if (time_outs) r += gamma * (s_val[i] * (time_outs[i] ? 1.0f : 0.0f));
-  s_rew[i] = r; s_done[i] = dones[i] ? 1.0f : 0.0f;
+  s_rew[i] = r; s_done[i] = done ? 1.0f : 0.0f;
 }
 
 // RolloutStorage.compute_returns: GAE reverse scan, one thread per env; advantages = returns - values
@@ -155,19 +162,14 @@ __global__ void k_normalize(size_t n, float* __restrict__ x, float* __restrict__
 __global__ void k_reduce_slabs(int n, int S, const float* __restrict__ slabs, float* __restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s = 0.0f;
-  for (int k = 0; k < S; ++k) s += slabs[(size_t)k * n + i];
-  out[i] = s;
-}
-
-// column sums of G[M, N] (bias gradients): stage 1 -> slabs[chunk][n]
-__global__ void k_colsum1(int M, int N, int ld, int rows_per_block, const float* __restrict__ G, float* __restrict__ slabs) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  float s = 0.0f;
-  for (int r = r0; r < r1; ++r) s += G[(size_t)r * ld + n];
-  slabs[(size_t)blockIdx.y * N + n] = s;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int k = 0;
+  for (; k + 3 < S; k += 4) {
+    s0 += slabs[(size_t)k * n + i]; s1 += slabs[(size_t)(k + 1) * n + i];
+    s2 += slabs[(size_t)(k + 2) * n + i]; s3 += slabs[(size_t)(k + 3) * n + i];
+  }
+  for (; k < S; ++k) s0 += slabs[(size_t)k * n + i];
+  out[i] = (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------- minibatch gather
@@ -208,7 +210,9 @@ __global__ void k_thin_fwd(int M, int K, int NO, const float* __restrict__ X, co
 // backward of the thin head: Gprev[M,K] = (dY[M,NO] W[NO,K]) * ELU'(H[M,K]);  slabs: dW[NO,K] and db[NO] partials
 template <int NO_MAX>
 __global__ void k_thin_bwd(int M, int K, int NO, int rows_per_block, const float* __restrict__ dY, const float* __restrict__ H,
-                           const float* __restrict__ W, float* __restrict__ Gprev, float* __restrict__ slabsW, float* __restrict__ slabsB) {
+                           const float* __restrict__ W, float* __restrict__ Gprev, float* __restrict__ slabs) {
+  float* slabsW = slabs + (size_t)blockIdx.x * ((size_t)NO * K + NO);
+  float* slabsB = slabsW + (size_t)NO * K;
   int k = threadIdx.x;              // blockDim.x >= K
   int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float w[NO_MAX], dw[NO_MAX], db[NO_MAX];
@@ -222,8 +226,8 @@ __global__ void k_thin_bwd(int M, int K, int NO, int rows_per_block, const float
   }
 #pragma unroll
   for (int o = 0; o < NO_MAX; ++o) if (o < NO) {
-    if (k < K) slabsW[((size_t)blockIdx.x * NO + o) * K + k] = dw[o];
-    if (k == 0) slabsB[(size_t)blockIdx.x * NO + o] = db[o];
+    if (k < K) slabsW[(size_t)o * K + k] = dw[o];
+    if (k == 0) slabsB[o] = db[o];
   }
 }
 
@@ -398,7 +402,7 @@ static void ppo_plan(PpoAlg* a) {
   for (int i = 0; i < a->actor.nl; ++i) { mw = std::max(mw, a->actor.l[i].out); maxw = std::max(maxw, (size_t)a->actor.l[i].in * a->actor.l[i].out); }
   for (int i = 0; i < a->critic.nl; ++i) { mw = std::max(mw, a->critic.l[i].out); maxw = std::max(maxw, (size_t)a->critic.l[i].in * a->critic.l[i].out); }
   a->max_width = mw;
-  a->splits = 48;
+  a->splits = 64;
   size_t R = a->max_rows, w = 0;
   auto take = [&](size_t n) { size_t at = w; w += (n + 63) & ~(size_t)63; return at; };
   a->w_xa = take(R * c.num_obs); a->w_xc = take(R * c.num_critic_obs); a->w_act = take(R * c.num_actions);
@@ -408,8 +412,8 @@ static void ppo_plan(PpoAlg* a) {
   for (int i = 0; i < a->critic.nl; ++i) a->w_hc[i] = take(R * a->critic.l[i].out);
   a->w_dmean = take(R * c.num_actions); a->w_dvalue = take(R);
   a->w_g[0] = take(R * mw); a->w_g[1] = take(R * mw);
-  size_t thin_blocks = (R + 255) / 256;
-  a->w_slabs = take(std::max<size_t>((size_t)a->splits * maxw, thin_blocks * 8 * 1024) + thin_blocks * 8 + (size_t)RED_BLOCKS * mw);
+  size_t thin_blocks = (R + 31) / 32;
+  a->w_slabs = take(std::max<size_t>((size_t)a->splits * (maxw + mw), thin_blocks * (8 * 1024 + 8)));
   a->w_partial = take((size_t)RED_BLOCKS * 16);
   a->w_lastval = take(c.num_envs);
   a->w_total = w;
@@ -429,8 +433,7 @@ static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const si
     } else {
       GemmArgs g{};
       g.A = in; g.B = P + L.w; g.C = out; g.M = M; g.N = L.out; g.K = L.in; g.lda = L.in; g.ldb = L.in; g.ldc = L.out; g.bias = P + L.b;
-      if (M >= 8192 && L.out >= 128) pf_gemm_launch<128, 128, true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
-      else pf_gemm_launch<64, 64, true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
+      pf_gemm_auto<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
     }
     in = out;
   }
@@ -446,45 +449,36 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
   float* gnext = ws + a->w_g[1];
   {
     const Layer& L = n.l[last];
-    int rows_per_block = 256, nblk = (M + rows_per_block - 1) / rows_per_block;
+    int rows_per_block = 32, nblk = (M + rows_per_block - 1) / rows_per_block;
     int threads = (L.in + 63) / 64 * 64;
-    float* slabsW = slabs; float* slabsB = slabs + (size_t)nblk * L.out * L.in;
     hipLaunchKernelGGL((k_thin_bwd<8>), dim3(nblk), dim3(threads), 0, s, M, L.in, L.out, rows_per_block, dHead, ws + w_h[last - 1], P + L.w,
-                       gcur, slabsW, slabsB);
-    int nw = L.out * L.in;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, nblk, slabsW, G + L.w);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(1), dim3(64), 0, s, L.out, nblk, slabsB, G + L.b);
+                       gcur, slabs);
+    int nw = L.out * L.in + L.out;       // W then b, contiguous in the flat gradient buffer
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, nblk, slabs, G + L.w);
   }
   for (int i = last - 1; i >= 0; --i) {
     const Layer& L = n.l[i];
     const float* in = i == 0 ? X : ws + w_h[i - 1];
-    // dW_i = gcur[M, out]^T * in[M, in]   (split over rows, deterministic slab reduce)
+    // dW_i = gcur[M, out]^T * in[M, in] and db_i = column sums of gcur, both as split-K slabs [S][out*in + out]
+    // (rows split across blockIdx.z; deterministic slab reduce straight into the flat gradient: W then b)
     {
       GemmArgs g{};
       g.A = gcur; g.B = in; g.C = slabs; g.M = L.out; g.N = L.in; g.K = M; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
-      int per = ((M + a->splits - 1) / a->splits + 31) / 32 * 32;
+      int tiles = ((L.out + 127) / 128) * ((L.in + 127) / 128);
+      int want = std::max(1, std::min(a->splits, 512 / std::max(tiles, 1)));
+      int per = ((M + want - 1) / want + 31) / 32 * 32;
       int S = (M + per - 1) / per;
       g.k_per_split = per;
-      if (L.out >= 128 && L.in >= 128) pf_gemm_launch<128, 128, false, false, GEMM_EPI_NONE>(g, S, s);
-      else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE>(g, S, s);
-      int nw = L.out * L.in;
+      pf_gemm_auto<false, false, GEMM_EPI_NONE, true>(g, S, s);
+      int nw = L.out * L.in + L.out;
       hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, S, slabs, G + L.w);
-    }
-    // db_i = column sums of gcur
-    {
-      float* cs = slabs + (size_t)a->splits * L.out * L.in;
-      int rpb = (M + RED_BLOCKS - 1) / RED_BLOCKS;
-      int nchunk = (M + rpb - 1) / rpb;
-      hipLaunchKernelGGL(k_colsum1, dim3((L.out + 63) / 64, nchunk), dim3(64), 0, s, M, L.out, L.out, rpb, gcur, cs);
-      hipLaunchKernelGGL(k_reduce_slabs, dim3((L.out + 255) / 256), dim3(256), 0, s, L.out, nchunk, cs, G + L.b);
     }
     if (i > 0) {
       // dZ_{i-1} = (gcur[M,out] * W_i[out,in]) * ELU'(h_{i-1})
       GemmArgs g{};
       g.A = gcur; g.B = P + L.w; g.C = gnext; g.M = M; g.N = L.in; g.K = L.out; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
       g.H = ws + w_h[i - 1]; g.ldh = L.in;
-      if (M >= 8192 && L.in >= 128) pf_gemm_launch<128, 128, true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
-      else pf_gemm_launch<64, 64, true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
+      pf_gemm_auto<true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
       std::swap(gcur, gnext);
     }
   }
@@ -557,7 +551,8 @@ int ppo_process_env_step(PpoAlg* a, int32_t t, const float* d_rew, const uint8_t
   if (t < 0 || t >= c.num_steps) { pf_set_error("ppo_process_env_step: transition index out of range"); return 1; }
   size_t tn = (size_t)t * c.num_envs;
   hipLaunchKernelGGL(k_process, dim3((c.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, c.num_envs, c.gamma, d_rew, d_dones,
-                     d_time_outs, a->b.d_values + tn, a->b.d_rewards + tn, a->b.d_dones + tn);
+                     d_time_outs, a->b.d_values + tn, a->b.d_rewards + tn, a->b.d_dones + tn,
+                     a->b.d_ep_stats ? a->b.d_ep_return : nullptr, a->b.d_ep_length, a->b.d_ep_stats);
   PPO_HIP_OK(hipGetLastError());
   return 0;
 }

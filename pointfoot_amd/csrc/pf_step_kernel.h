@@ -10,8 +10,9 @@
 #include "../../include/pointfoot_hip.h"
 #include "pf_simt.h"
 
-#define PF_REC_MAX 256
-#define PF_MAXC 8
+#define PF_REC_MAX 160
+#define PF_MAXC 6          /* contacts kept per robot (first active in sphere order: feet first) */
+#define PF_KSPH 24         /* collision spheres staged per robot by the kernel instances built so far */
 
 // ------------------------------------------------------------------------------------ small math
 PF_DEV float pf_clip(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -121,7 +122,48 @@ struct PfKernel {
   static constexpr int RFREE = CROWS + ND;    // extra right-hand side: free acceleration
   static constexpr int NROWS = RFREE + 1;
 
+
+  // Record offsets as compile-time constants (same rule as pf_compute_layout with num_actions == ND; checked against the
+  // runtime PfLayout in pf_create): addresses fold into ds_read/ds_write immediates instead of living in SGPRs.
+  struct LC {
+    static constexpr int root = 0, dof_pos = root + 13, dof_vel = dof_pos + ND, actions = dof_vel + ND, last_actions = actions + ND,
+                         last_dof_vel = last_actions + ND, last_root_vel = last_dof_vel + ND, commands = last_root_vel + 6,
+                         torques = commands + 4, base_lin_vel = torques + ND, base_ang_vel = base_lin_vel + 3,
+                         projected_gravity = base_ang_vel + 3, feet_air_time = projected_gravity + 3,
+                         last_feet_air_time = feet_air_time + NF, cur_max_feet_height = last_feet_air_time + NF,
+                         last_max_feet_height = cur_max_feet_height + NF, feet_height = last_max_feet_height + NF,
+                         contact_filt = feet_height + NF, first_contact = contact_filt + NF, last_contacts = first_contact + NF,
+                         contact_forces = last_contacts + NF, feet_pos = contact_forces + 3 * NB, ext_force = feet_pos + 3 * NF,
+                         env_origin = ext_force + 4, friction = env_origin + 3, added_mass = friction + 1, added_com = added_mass + 1,
+                         episode_sums = added_com + 3;
+  };
+  static bool layout_matches(const PfLayout& L) {
+    return L.root == LC::root && L.dof_pos == LC::dof_pos && L.dof_vel == LC::dof_vel && L.actions == LC::actions &&
+           L.last_actions == LC::last_actions && L.last_dof_vel == LC::last_dof_vel && L.last_root_vel == LC::last_root_vel &&
+           L.commands == LC::commands && L.torques == LC::torques && L.base_lin_vel == LC::base_lin_vel &&
+           L.base_ang_vel == LC::base_ang_vel && L.projected_gravity == LC::projected_gravity && L.feet_air_time == LC::feet_air_time &&
+           L.last_feet_air_time == LC::last_feet_air_time && L.cur_max_feet_height == LC::cur_max_feet_height &&
+           L.last_max_feet_height == LC::last_max_feet_height && L.feet_height == LC::feet_height && L.contact_filt == LC::contact_filt &&
+           L.first_contact == LC::first_contact && L.last_contacts == LC::last_contacts && L.contact_forces == LC::contact_forces &&
+           L.feet_pos == LC::feet_pos && L.ext_force == LC::ext_force && L.env_origin == LC::env_origin && L.friction == LC::friction &&
+           L.added_mass == LC::added_mass && L.added_com == LC::added_com && L.episode_sums == LC::episode_sums;
+  }
+
+  // The robot model, re-packed to this instance's sizes and staged in LDS once per launch: the per-body / per-sphere
+  // tables are indexed by lane, so reading them from global memory would put an L2 round trip into every phase.
+  struct ModelS {
+    int nsph, n_term, n_pen;
+    int parent[NB], depth[NB], subtree[NB], dof_of_body[NB], body_of_dof[ND], feet_body[NF];
+    int term_body[PF_MAX_TERM], pen_body[PF_MAX_PEN];
+    float joint_pos[NB][3], joint_rot[NB][9], joint_axis[NB][3];
+    float mass[NB], com[NB][3], inertia[NB][6];
+    float q_lo[ND], q_hi[ND], vel_limit[ND];
+    int sph_body[PF_KSPH];
+    float sph_pos[PF_KSPH][3], sph_radius[PF_KSPH];
+  };
+
   struct Shared {
+    ModelS mdl;
     float rec[PF_REC_MAX];
     float Rw[NB][9], r[NB][3], ax[NB][3];
     float Sj[NB][6], V[NB][6], A[NB][6];      // {ang, lin@O}
@@ -135,10 +177,12 @@ struct PfKernel {
     float rb[NROWS], rAinv[NROWS], lam[NROWS];
     float cA[MAXC][9], cdir[MAXC][9];
     int cbody[MAXC], con_sph[MAXC], lim_dof[ND], lim_side[ND];
-    float sphx[PF_MAX_SPHERES][3], sphn[PF_MAX_SPHERES][3], sphd[PF_MAX_SPHERES];
-    int sphact[PF_MAX_SPHERES];
-    float heights[PF_MAX_HPTS];
+    float sphx[PF_KSPH][3], sphn[PF_KSPH][3], sphd[PF_KSPH];
+    int sphact[PF_KSPH];
   };
+  // the height scan (post-physics only) reuses the constraint-row storage (physics only)
+  static_assert(NROWS * NVP >= PF_MAX_HPTS, "height scan does not fit the aliased row storage");
+  PF_DEV float* heights_of(Shared& sh) { return &sh.J[0][0]; }
 
   // ------------------------------------------------------------------ terrain
   // point_foot.py:1100-1112 for one point; exact float32 op order of the reference, no FMA contraction
@@ -186,25 +230,25 @@ struct PfKernel {
       // branch-free on purpose: hipcc (ROCm 7.2) miscompiled the if / else-if / else form of this body
       // (lane index left undefined on the 'T' path -> wild load of torque_limits); selects are also cheaper.
       float qp = qsrc[k * qstride], qv = qsrc[k * qstride + voff];
-      float as = sh.rec[L.actions + k] * c.action_scale;
+      float as = sh.rec[LC::actions + k] * c.action_scale;
       float lim = c.torque_limits[k];
       float tP = c.p_gains[k] * ((as + c.default_dof_pos[k]) - qp) - c.d_gains[k] * qv;
-      float tV = c.p_gains[k] * (as - qv) - c.d_gains[k] * (qv - sh.rec[L.last_dof_vel + k]) / c.sim_dt;
+      float tV = c.p_gains[k] * (as - qv) - c.d_gains[k] * (qv - sh.rec[LC::last_dof_vel + k]) / c.sim_dt;
       float t = c.control_type == PF_CTRL_P ? tP : (c.control_type == PF_CTRL_V ? tV : as);
-      sh.rec[L.torques + k] = pf_clip(t, -lim, lim);
+      sh.rec[LC::torques + k] = pf_clip(t, -lim, lim);
     }
     PF_SYNC();
   }
 
   // ------------------------------------------------------------------ forward kinematics (+ velocities)
   template <bool WITH_VEL>
-  PF_DEV void kinematics(Shared& sh, const PfModel& m, const PfConfig& c, const PfLayout& L) {
+  PF_DEV void kinematics(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L) {
     const float* S = sh.rec;
     int maxdepth = 0;
 #pragma unroll
     for (int i = 0; i < NB; ++i) maxdepth = m.depth[i] > maxdepth ? m.depth[i] : maxdepth;
     PF_LANES(i, 1) {
-      const float* q = S + L.root + 3;
+      const float* q = S + LC::root + 3;
       float x = q[0], y = q[1], z = q[2], w = q[3];
       float* R = sh.Rw[0];
       R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
@@ -212,7 +256,7 @@ struct PfKernel {
       R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
       sh.r[0][0] = 0.0f; sh.r[0][1] = 0.0f; sh.r[0][2] = 0.0f;
       if (WITH_VEL) {
-        const float* vb = S + L.root + 7; const float* wb = S + L.root + 10;
+        const float* vb = S + LC::root + 7; const float* wb = S + LC::root + 10;
         float wxv[3]; pf_cross(wb, vb, wxv);
         for (int t = 0; t < 3; ++t) {
           sh.V[0][t] = wb[t]; sh.V[0][3 + t] = vb[t];
@@ -234,7 +278,7 @@ struct PfKernel {
         if (k >= 0) {
           const float* a = m.joint_axis[i];
           float aw[3]; pf_mat_vec(Rj, a, aw);
-          float th = S[L.dof_pos + k];
+          float th = S[LC::dof_pos + k];
           float cs = cosf(th), sn = sinf(th), t1 = 1.0f - cs;
           float Ra[9] = {t1 * a[0] * a[0] + cs, t1 * a[0] * a[1] - sn * a[2], t1 * a[0] * a[2] + sn * a[1],
                          t1 * a[0] * a[1] + sn * a[2], t1 * a[1] * a[1] + cs, t1 * a[1] * a[2] - sn * a[0],
@@ -243,7 +287,7 @@ struct PfKernel {
           sh.ax[i][0] = aw[0]; sh.ax[i][1] = aw[1]; sh.ax[i][2] = aw[2];
           if (WITH_VEL) {
             float sl[3]; pf_cross(ri, aw, sl);
-            float qd = S[L.dof_vel + k];
+            float qd = S[LC::dof_vel + k];
             float Vi[6];
             for (int t = 0; t < 3; ++t) { sh.Sj[i][t] = aw[t]; sh.Sj[i][3 + t] = sl[t]; Vi[t] = sh.V[p][t] + qd * aw[t]; Vi[3 + t] = sh.V[p][3 + t] + qd * sl[t]; }
             float ca[3], c1[3], c2[3];
@@ -266,7 +310,7 @@ struct PfKernel {
   }
 
   // ------------------------------------------------------------------ one physics substep of sim_dt
-  PF_DEV void substep(Shared& sh, const PfModel& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, bool apply_ext) {
+  PF_DEV void substep(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, bool apply_ext) {
     float* S = sh.rec;
     const float dt = c.sim_dt;
     kinematics<true>(sh, m, c, L);
@@ -277,10 +321,10 @@ struct PfKernel {
       float Il[6];
       for (int t = 0; t < 6; ++t) Il[t] = m.inertia[i][t];
       if (i == 0) {   // base mass / COM randomisation (:466-477), inertia scaled with mass
-        float added = S[L.added_mass];
+        float added = S[LC::added_mass];
         float sc = (mass + added) / mass;
         mass += added;
-        for (int t = 0; t < 3; ++t) cl[t] += S[L.added_com + t];
+        for (int t = 0; t < 3; ++t) cl[t] += S[LC::added_com + t];
         for (int t = 0; t < 6; ++t) Il[t] *= sc;
       }
       const float* R = sh.Rw[i];
@@ -307,7 +351,7 @@ struct PfKernel {
       pf_cross(Vi, IV, x1); pf_cross(Vi + 3, IV + 3, x2); pf_cross(Vi, IV + 3, x3);
       for (int t = 0; t < 3; ++t) { sh.f[i][t] = IA[t] + x1[t] + x2[t]; sh.f[i][3 + t] = IA[3 + t] + x3[t]; }
       if (i == 0 && apply_ext)
-        for (int t = 0; t < 3; ++t) sh.f[0][3 + t] -= S[L.ext_force + t];
+        for (int t = 0; t < 3; ++t) sh.f[0][3 + t] -= S[LC::ext_force + t];
     }
     PF_SYNC();
     // ---- composites over DFS-contiguous subtrees
@@ -364,15 +408,15 @@ struct PfKernel {
     }
     PF_LANES(a, NV) {
       float bv, vo;
-      if (a < 3) { bv = sh.fc[0][3 + a]; vo = S[L.root + 7 + a]; }
-      else if (a < 6) { bv = sh.fc[0][a - 3]; vo = S[L.root + 7 + a]; }
+      if (a < 3) { bv = sh.fc[0][3 + a]; vo = S[LC::root + 7 + a]; }
+      else if (a < 6) { bv = sh.fc[0][a - 3]; vo = S[LC::root + 7 + a]; }
       else {
         int k = a - 6, i = m.body_of_dof[k];
         bv = pf_dot3(sh.Sj[i], sh.fc[i]) + pf_dot3(sh.Sj[i] + 3, sh.fc[i] + 3);
-        vo = S[L.dof_vel + k];
+        vo = S[LC::dof_vel + k];
       }
       sh.bias[a] = bv; sh.vold[a] = vo;
-      float rhs = -bv + (a >= 6 ? S[L.torques + a - 6] : 0.0f);
+      float rhs = -bv + (a >= 6 ? S[LC::torques + a - 6] : 0.0f);
       sh.J[RFREE][a] = rhs; sh.W[RFREE][a] = rhs;
     }
     PF_SYNC();
@@ -398,9 +442,9 @@ struct PfKernel {
       float xs[3]; pf_mat_vec(sh.Rw[i], m.sph_pos[s], xs);
       for (int t = 0; t < 3; ++t) xs[t] += sh.r[i][t];
       float h, n[3];
-      terrain_query(c, hs, S[L.root] + xs[0], S[L.root + 1] + xs[1], &h, n);
+      terrain_query(c, hs, S[LC::root] + xs[0], S[LC::root + 1] + xs[1], &h, n);
       float rad = m.sph_radius[s];
-      float dist = (S[L.root + 2] + xs[2] - h) * n[2] - rad;
+      float dist = (S[LC::root + 2] + xs[2] - h) * n[2] - rad;
       sh.sphact[s] = dist < c.contact_offset ? 1 : 0;
       sh.sphd[s] = dist;
       for (int t = 0; t < 3; ++t) { sh.sphx[s][t] = xs[t] - rad * n[t]; sh.sphn[s][t] = n[t]; }
@@ -465,7 +509,7 @@ struct PfKernel {
     PF_SYNC();
     // ---- joint-limit rows (need the free velocity)
     PF_LANES(k, ND) {
-      float q = S[L.dof_pos + k], qn = q + dt * sh.vel[6 + k];
+      float q = S[LC::dof_pos + k], qn = q + dt * sh.vel[6 + k];
       float lo = m.q_lo[k], hi = m.q_hi[k];
       int side = 0;
       if (q < lo || qn < lo) side = 1; else if (q > hi || qn > hi) side = -1;
@@ -482,7 +526,7 @@ struct PfKernel {
       int rr = CROWS + idx;
       sh.lim_dof[idx] = k;
       for (int a = 0; a < NV; ++a) { float v = (a == 6 + k) ? (float)side : 0.0f; sh.J[rr][a] = v; sh.W[rr][a] = v; }
-      float q = S[L.dof_pos + k];
+      float q = S[LC::dof_pos + k];
       float viol = side > 0 ? m.q_lo[k] - q : q - m.q_hi[k];
       sh.rb[rr] = viol > 0.0f ? fminf(0.2f * viol / dt, 10.0f * c.max_depenetration_vel) : viol / dt;
       sh.lam[rr] = 0.0f;
@@ -499,7 +543,7 @@ struct PfKernel {
     }
     PF_SYNC();
     // ---- projected Gauss-Seidel (uniform impulse math, lane-parallel velocity update)
-    const float mu = 0.5f * (S[L.friction] + c.terrain_friction);
+    const float mu = 0.5f * (S[LC::friction] + c.terrain_friction);
     for (int it = 0; it < c.solver_iterations; ++it) {
       for (int ci = 0; ci < ncon; ++ci) {
         int r0 = 3 * ci;
@@ -538,8 +582,8 @@ struct PfKernel {
     PF_LANES(k, ND) {
       float vl = m.vel_limit[k];
       float v = fminf(fmaxf(sh.vel[6 + k], -vl), vl);
-      S[L.dof_vel + k] = v;
-      S[L.dof_pos + k] += dt * v;
+      S[LC::dof_vel + k] = v;
+      S[LC::dof_pos + k] += dt * v;
     }
     PF_LANES(i, NB) {
       float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
@@ -550,25 +594,25 @@ struct PfKernel {
           Fx += l * sh.cdir[ci][3 * d]; Fy += l * sh.cdir[ci][3 * d + 1]; Fz += l * sh.cdir[ci][3 * d + 2];
         }
       }
-      S[L.contact_forces + 3 * i] = Fx; S[L.contact_forces + 3 * i + 1] = Fy; S[L.contact_forces + 3 * i + 2] = Fz;
+      S[LC::contact_forces + 3 * i] = Fx; S[LC::contact_forces + 3 * i + 1] = Fy; S[LC::contact_forces + 3 * i + 2] = Fz;
     }
     {
       float w0 = sh.vel[3], w1 = sh.vel[4], w2 = sh.vel[5];
-      float qx = S[L.root + 3], qy = S[L.root + 4], qz = S[L.root + 5], qw = S[L.root + 6];
+      float qx = S[LC::root + 3], qy = S[LC::root + 4], qz = S[LC::root + 5], qw = S[LC::root + 6];
       float hx = 0.5f * dt * w0, hy = 0.5f * dt * w1, hz = 0.5f * dt * w2;
       float nx = qx + (hx * qw + hy * qz - hz * qy);
       float ny = qy + (-hx * qz + hy * qw + hz * qx);
       float nz = qz + (hx * qy - hy * qx + hz * qw);
       float nw = qw + (-hx * qx - hy * qy - hz * qz);
       float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
-      float p0 = S[L.root] + dt * sh.vel[0], p1 = S[L.root + 1] + dt * sh.vel[1], p2 = S[L.root + 2] + dt * sh.vel[2];
+      float p0 = S[LC::root] + dt * sh.vel[0], p1 = S[LC::root + 1] + dt * sh.vel[1], p2 = S[LC::root + 2] + dt * sh.vel[2];
       float v6[6];
       for (int t = 0; t < 6; ++t) v6[t] = sh.vel[t];
       PF_SYNC();
       PF_ONE {
-        S[L.root] = p0; S[L.root + 1] = p1; S[L.root + 2] = p2;
-        S[L.root + 3] = nx * inv; S[L.root + 4] = ny * inv; S[L.root + 5] = nz * inv; S[L.root + 6] = nw * inv;
-        for (int t = 0; t < 6; ++t) S[L.root + 7 + t] = v6[t];
+        S[LC::root] = p0; S[LC::root + 1] = p1; S[LC::root + 2] = p2;
+        S[LC::root + 3] = nx * inv; S[LC::root + 4] = ny * inv; S[LC::root + 5] = nz * inv; S[LC::root + 6] = nw * inv;
+        for (int t = 0; t < 6; ++t) S[LC::root + 7 + t] = v6[t];
       }
     }
     PF_SYNC();
@@ -576,19 +620,26 @@ struct PfKernel {
 
   // W[row] <- M^-1 J[row]^T by forward/back substitution on the in-place Cholesky factor; Ainv = 1/(J.W)
   PF_DEV void solve_one(Shared& sh, int rr) {
-    float* w = sh.W[rr];
+    float w[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) w[i] = sh.W[rr][i];
+#pragma unroll
     for (int i = 0; i < NV; ++i) {
       float s = w[i];
+#pragma unroll
       for (int t = 0; t < i; ++t) s -= sh.M[i][t] * w[t];
       w[i] = s * sh.dinv[i];
     }
+#pragma unroll
     for (int i = NV - 1; i >= 0; --i) {
       float s = w[i];
+#pragma unroll
       for (int t = i + 1; t < NV; ++t) s -= sh.M[t][i] * w[t];
       w[i] = s * sh.dinv[i];
     }
     float a = 0.0f;
-    for (int t = 0; t < NV; ++t) a += sh.J[rr][t] * w[t];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) { a += sh.J[rr][t] * w[t]; sh.W[rr][t] = w[t]; }
     sh.rAinv[rr] = 1.0f / fmaxf(a, 1e-9f);
   }
   PF_DEV void solve_rows(Shared& sh, int nrows, bool with_free) {
@@ -604,15 +655,16 @@ struct PfKernel {
 #pragma clang fp contract(off)
 #endif
     const float* S = sh.rec;
+    const float* hts = heights_of(sh);
     const int no = c.num_obs, np_ = c.num_priv_obs, na = c.num_actions;
     PF_LANES(i, no) {
       float v;
-      if (i < 3) v = S[L.base_ang_vel + i] * c.obs_scale_ang_vel;
-      else if (i < 6) v = S[L.projected_gravity + i - 3];
-      else if (i < 6 + ND) v = (S[L.dof_pos + i - 6] - c.default_dof_pos[i - 6]) * c.obs_scale_dof_pos;
-      else if (i < 6 + 2 * ND) v = S[L.dof_vel + i - 6 - ND] * c.obs_scale_dof_vel;
-      else if (i < 6 + 2 * ND + na) v = S[L.actions + i - 6 - 2 * ND];
-      else { int k = i - 6 - 2 * ND - na; v = S[L.commands + k] * c.commands_scale[k]; }
+      if (i < 3) v = S[LC::base_ang_vel + i] * c.obs_scale_ang_vel;
+      else if (i < 6) v = S[LC::projected_gravity + i - 3];
+      else if (i < 6 + ND) v = (S[LC::dof_pos + i - 6] - c.default_dof_pos[i - 6]) * c.obs_scale_dof_pos;
+      else if (i < 6 + 2 * ND) v = S[LC::dof_vel + i - 6 - ND] * c.obs_scale_dof_vel;
+      else if (i < 6 + 2 * ND + na) v = S[LC::actions + i - 6 - 2 * ND];
+      else { int k = i - 6 - 2 * ND - na; v = S[LC::commands + k] * c.commands_scale[k]; }
       if (c.add_noise) v += (2.0f * rnd(c, L, inj, env, step, L.r_obs + i) - 1.0f) * c.obs_noise_vec[i];
       v = pf_clip(v, -c.clip_obs, c.clip_obs);
       B.d_obs[(size_t)env * no + i] = v;
@@ -620,7 +672,7 @@ struct PfKernel {
     }
     if (B.d_priv && c.measure_heights) {
       PF_LANES(j, c.num_height_points) {    // :367-373
-        float h = pf_clip((S[L.root + 2] - 0.5f) - sh.heights[j], -1.0f, 1.0f) * c.obs_scale_height;
+        float h = pf_clip((S[LC::root + 2] - 0.5f) - hts[j], -1.0f, 1.0f) * c.obs_scale_height;
         if (c.add_noise) h += (2.0f * rnd(c, L, inj, env, step, L.r_priv + j) - 1.0f) * c.priv_height_noise;
         B.d_priv[(size_t)env * np_ + no + j] = pf_clip(h, -c.clip_obs, c.clip_obs);
       }
@@ -628,16 +680,16 @@ struct PfKernel {
   }
 
   // ------------------------------------------------------------------ reset_idx for this env (:249-299)
-  PF_DEV void reset_env(Shared& sh, const PfModel& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
+  PF_DEV void reset_env(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
 #if !defined(PF_HOST_EMU)
 #pragma clang fp contract(off)
 #endif
     float* S = sh.rec;
     if (c.curriculum) {     // :613-636
-      float dx = S[L.root] - S[L.env_origin], dy = S[L.root + 1] - S[L.env_origin + 1];
+      float dx = S[LC::root] - S[LC::env_origin], dy = S[LC::root + 1] - S[LC::env_origin + 1];
       float dist = sqrtf(dx * dx + dy * dy);
       bool up = dist > c.terrain_length / 2.0f;
-      float cn = sqrtf(S[L.commands] * S[L.commands] + S[L.commands + 1] * S[L.commands + 1]);
+      float cn = sqrtf(S[LC::commands] * S[LC::commands] + S[LC::commands + 1] * S[LC::commands + 1]);
       bool down = (dist < cn * c.max_episode_length_s * 0.5f) && !up;
       int lvl = B.d_terrain_level[env] + (up ? 1 : 0) - (down ? 1 : 0);
       if (lvl >= c.max_terrain_level) {
@@ -648,28 +700,28 @@ struct PfKernel {
       const float* o = B.d_terrain_origins + ((size_t)lvl * c.terrain_num_cols + B.d_terrain_type[env]) * 3;
       float o0 = o[0], o1 = o[1], o2 = o[2];
       PF_SYNC();
-      PF_ONE { B.d_terrain_level[env] = lvl; S[L.env_origin] = o0; S[L.env_origin + 1] = o1; S[L.env_origin + 2] = o2; }
+      PF_ONE { B.d_terrain_level[env] = lvl; S[LC::env_origin] = o0; S[LC::env_origin + 1] = o1; S[LC::env_origin + 2] = o2; }
       PF_SYNC();
     }
     PF_LANES(k, ND) {       // :549-559
-      S[L.dof_pos + k] = c.default_dof_pos[k] * ((1.5f - 0.5f) * rnd(c, L, inj, env, step, L.r_dof + k) + 0.5f);
-      S[L.dof_vel + k] = 0.0f;
+      S[LC::dof_pos + k] = c.default_dof_pos[k] * ((1.5f - 0.5f) * rnd(c, L, inj, env, step, L.r_dof + k) + 0.5f);
+      S[LC::dof_vel + k] = 0.0f;
     }
     PF_LANES(i, 13) {       // :566-584
       float v = c.base_init_state[i];
-      if (i < 3) v += S[L.env_origin + i];
+      if (i < 3) v += S[LC::env_origin + i];
       if (i < 2 && c.custom_origins) v += (1.0f - (-1.0f)) * rnd(c, L, inj, env, step, L.r_xy + i) + (-1.0f);
       if (i >= 7) v = (0.5f - (-0.5f)) * rnd(c, L, inj, env, step, L.r_vel + i - 7) + (-0.5f);
-      S[L.root + i] = v;
+      S[LC::root + i] = v;
     }
     PF_LANES(f, NF) {       // :290-299
-      S[L.feet_air_time + f] = 0.0f; S[L.last_feet_air_time + f] = 0.0f;
-      S[L.cur_max_feet_height + f] = 0.0f; S[L.last_max_feet_height + f] = 0.0f;
+      S[LC::feet_air_time + f] = 0.0f; S[LC::last_feet_air_time + f] = 0.0f;
+      S[LC::cur_max_feet_height + f] = 0.0f; S[LC::last_max_feet_height + f] = 0.0f;
     }
     int nsum = c.num_rewards + (c.termination_scale != 0.0f ? 1 : 0);
     PF_LANES(ri, nsum) {    // :276-280
-      if (B.d_reset_stats) PF_ATOMIC_ADD(B.d_reset_stats + ri, S[L.episode_sums + ri]);
-      S[L.episode_sums + ri] = 0.0f;
+      if (B.d_reset_stats) PF_ATOMIC_ADD(B.d_reset_stats + ri, S[LC::episode_sums + ri]);
+      S[LC::episode_sums + ri] = 0.0f;
     }
     PF_ONE { if (B.d_reset_stats) PF_ATOMIC_ADD(B.d_reset_stats + PF_MAX_REWARDS, 1.0f); }
     PF_SYNC();
@@ -677,7 +729,25 @@ struct PfKernel {
 
   // ------------------------------------------------------------------ the whole step for env `env`
   PF_DEV void run(Shared& sh, const PfStepArgs& g, int env) {
-    const PfModel& m = *g.model; const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
+    const PfModel& gm = *g.model; const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
+    ModelS& ms = sh.mdl;
+    PF_LANES(i, NB) {
+      ms.parent[i] = gm.parent[i]; ms.depth[i] = gm.depth[i]; ms.subtree[i] = gm.subtree[i]; ms.dof_of_body[i] = gm.dof_of_body[i];
+      ms.mass[i] = gm.mass[i];
+      for (int t = 0; t < 3; ++t) { ms.joint_pos[i][t] = gm.joint_pos[i][t]; ms.joint_axis[i][t] = gm.joint_axis[i][t]; ms.com[i][t] = gm.com[i][t]; }
+      for (int t = 0; t < 9; ++t) ms.joint_rot[i][t] = gm.joint_rot[i][t];
+      for (int t = 0; t < 6; ++t) ms.inertia[i][t] = gm.inertia[i][t];
+    }
+    PF_LANES(k, ND) { ms.body_of_dof[k] = gm.body_of_dof[k]; ms.q_lo[k] = gm.q_lo[k]; ms.q_hi[k] = gm.q_hi[k]; ms.vel_limit[k] = gm.vel_limit[k]; }
+    PF_LANES(s2, PF_KSPH) {
+      ms.sph_body[s2] = gm.sph_body[s2]; ms.sph_radius[s2] = gm.sph_radius[s2];
+      for (int t = 0; t < 3; ++t) ms.sph_pos[s2][t] = gm.sph_pos[s2][t];
+    }
+    PF_LANES(f, NF) ms.feet_body[f] = gm.feet_body[f];
+    PF_LANES(t, PF_MAX_TERM) ms.term_body[t] = gm.term_body[t];
+    PF_LANES(t, PF_MAX_PEN) ms.pen_body[t] = gm.pen_body[t];
+    PF_ONE { ms.nsph = gm.nsph; ms.n_term = gm.n_term; ms.n_pen = gm.n_pen; }
+    const ModelS& m = ms;
     float* S = sh.rec;
     float* grow = B.d_state + (size_t)env * L.rec_floats;
     PF_LANES(i, L.rec_floats) S[i] = grow[i];
@@ -689,30 +759,31 @@ struct PfKernel {
       return;
     }
     if (g.mode == 2) {
-      PF_LANES(j, c.num_height_points) sh.heights[j] = B.d_measured_heights ? B.d_measured_heights[(size_t)env * c.num_height_points + j] : 0.0f;
+      float* hts = heights_of(sh);
+      PF_LANES(j, c.num_height_points) hts[j] = B.d_measured_heights ? B.d_measured_heights[(size_t)env * c.num_height_points + j] : 0.0f;
       PF_SYNC();
       observations(sh, c, L, B, inj, env, g.step_counter);
       return;
     }
-    PF_LANES(k, c.num_actions) S[L.actions + k] = pf_clip(g.actions[(size_t)env * c.num_actions + k], -c.clip_actions, c.clip_actions);   // :176-177
+    PF_LANES(k, c.num_actions) S[LC::actions + k] = pf_clip(g.actions[(size_t)env * c.num_actions + k], -c.clip_actions, c.clip_actions);   // :176-177
     PF_SYNC();
     if (inj.d_root) {
       // Python-layer parity mode: injected sim snapshots stand in for simulate()/refresh (:183-185, :200-202)
       torques(sh, c, L, inj.d_dof_pre + (size_t)env * ND * 2, 2, 1);
-      PF_LANES(k, ND) { S[L.dof_pos + k] = inj.d_dof_post[((size_t)env * ND + k) * 2]; S[L.dof_vel + k] = inj.d_dof_post[((size_t)env * ND + k) * 2 + 1]; }
-      PF_LANES(i, 13) S[L.root + i] = inj.d_root[(size_t)env * 13 + i];
-      PF_LANES(i, NB * 3) S[L.contact_forces + i] = inj.d_contact[(size_t)env * NB * 3 + i];
-      PF_LANES(i, NF * 3) S[L.feet_pos + i] = inj.d_feet_pos[(size_t)env * NF * 3 + i];
+      PF_LANES(k, ND) { S[LC::dof_pos + k] = inj.d_dof_post[((size_t)env * ND + k) * 2]; S[LC::dof_vel + k] = inj.d_dof_post[((size_t)env * ND + k) * 2 + 1]; }
+      PF_LANES(i, 13) S[LC::root + i] = inj.d_root[(size_t)env * 13 + i];
+      PF_LANES(i, NB * 3) S[LC::contact_forces + i] = inj.d_contact[(size_t)env * NB * 3 + i];
+      PF_LANES(i, NF * 3) S[LC::feet_pos + i] = inj.d_feet_pos[(size_t)env * NF * 3 + i];
       PF_SYNC();
     } else {
       for (int sub = 0; sub < c.decimation; ++sub) {     // :180-185
-        torques(sh, c, L, S + L.dof_pos, 1, L.dof_vel - L.dof_pos);
-        bool ext = sub == 0 && S[L.ext_force + 3] != 0.0f;
+        torques(sh, c, L, S + LC::dof_pos, 1, LC::dof_vel - LC::dof_pos);
+        bool ext = sub == 0 && S[LC::ext_force + 3] != 0.0f;
         substep(sh, m, c, L, B, ext);
-        if (ext) { PF_ONE { S[L.ext_force + 3] = 0.0f; } PF_SYNC(); }
+        if (ext) { PF_ONE { S[LC::ext_force + 3] = 0.0f; } PF_SYNC(); }
       }
       kinematics<false>(sh, m, c, L);
-      PF_LANES(e, NF * 3) { int f = e / 3, t = e - 3 * f; S[L.feet_pos + e] = S[L.root + t] + sh.r[m.feet_body[f]][t]; }
+      PF_LANES(e, NF * 3) { int f = e / 3, t = e - 3 * f; S[LC::feet_pos + e] = S[LC::root + t] + sh.r[m.feet_body[f]][t]; }
       PF_SYNC();
     }
     post_physics(sh, m, c, L, B, inj, env, g.step_counter);
@@ -720,22 +791,23 @@ struct PfKernel {
   }
 
   // ------------------------------------------------------------------ post_physics_step (:195-230)
-  PF_DEV void post_physics(Shared& sh, const PfModel& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
+  PF_DEV void post_physics(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
 #if !defined(PF_HOST_EMU)
 #pragma clang fp contract(off)
 #endif
     float* S = sh.rec;
+    float* hts = heights_of(sh);
     const int H = c.num_height_points;
     long long ep = B.d_episode_length[env] + 1;      // :204
-    float q[4] = {S[L.root + 3], S[L.root + 4], S[L.root + 5], S[L.root + 6]};
+    float q[4] = {S[LC::root + 3], S[LC::root + 4], S[LC::root + 5], S[LC::root + 6]};
     // :208-211 (uniform; lane 0 stores)
     float blv[3], bav[3], pg[3];
     {
-      float lv[3] = {S[L.root + 7], S[L.root + 8], S[L.root + 9]}, av[3] = {S[L.root + 10], S[L.root + 11], S[L.root + 12]}, gv[3] = {0.0f, 0.0f, -1.0f};
+      float lv[3] = {S[LC::root + 7], S[LC::root + 8], S[LC::root + 9]}, av[3] = {S[LC::root + 10], S[LC::root + 11], S[LC::root + 12]}, gv[3] = {0.0f, 0.0f, -1.0f};
       pf_quat_rotate_dir(q, lv, -1.0f, blv); pf_quat_rotate_dir(q, av, -1.0f, bav); pf_quat_rotate_dir(q, gv, -1.0f, pg);
     }
     // :212-213, :1048-1075 height scan — one point per lane
-    float root_z = S[L.root + 2];
+    float root_z = S[LC::root + 2];
     float hsum = 0.0f;
     if (c.measure_heights) {
       float qy[4] = {0.0f, 0.0f, q[2], q[3]};
@@ -747,9 +819,9 @@ struct PfKernel {
         if (c.terrain_type != PF_TERRAIN_PLANE) {
           float pl[3] = {c.height_px[j], c.height_py[j], 0.0f}, pw[3];
           pf_quat_apply(qy, pl, pw);
-          hv = height_raw(c, B.d_height_samples, pw[0] + S[L.root], pw[1] + S[L.root + 1]) * c.vscale;
+          hv = height_raw(c, B.d_height_samples, pw[0] + S[LC::root], pw[1] + S[LC::root + 1]) * c.vscale;
         }
-        sh.heights[j] = hv;
+        hts[j] = hv;
         if (B.d_measured_heights) B.d_measured_heights[(size_t)env * H + j] = hv;
         hsum += root_z - hv;
       }
@@ -757,34 +829,34 @@ struct PfKernel {
     }
     // :1114-1129 feet state machine
     PF_LANES(f, NF) {
-      bool first = S[L.first_contact + f] != 0.0f, filt = S[L.contact_filt + f] != 0.0f;
-      float air = S[L.feet_air_time + f];
-      S[L.last_feet_air_time + f] = first ? air : S[L.last_feet_air_time + f];
+      bool first = S[LC::first_contact + f] != 0.0f, filt = S[LC::contact_filt + f] != 0.0f;
+      float air = S[LC::feet_air_time + f];
+      S[LC::last_feet_air_time + f] = first ? air : S[LC::last_feet_air_time + f];
       if (filt) air = 0.0f * air;
       if (c.include_feet_height) {
-        float cm = S[L.cur_max_feet_height + f];
-        S[L.last_max_feet_height + f] = first ? cm : S[L.last_max_feet_height + f];
+        float cm = S[LC::cur_max_feet_height + f];
+        S[LC::last_max_feet_height + f] = first ? cm : S[LC::last_max_feet_height + f];
         if (filt) cm = 0.0f * cm;
         float hb = 0.0f;
-        if (c.terrain_type != PF_TERRAIN_PLANE) hb = height_raw(c, B.d_height_samples, S[L.feet_pos + 3 * f], S[L.feet_pos + 3 * f + 1]) * c.vscale;
-        float fh = S[L.feet_pos + 3 * f + 2] - hb;
-        S[L.feet_height + f] = fh;
-        S[L.cur_max_feet_height + f] = fmaxf(cm, fh);
+        if (c.terrain_type != PF_TERRAIN_PLANE) hb = height_raw(c, B.d_height_samples, S[LC::feet_pos + 3 * f], S[LC::feet_pos + 3 * f + 1]) * c.vscale;
+        float fh = S[LC::feet_pos + 3 * f + 2] - hb;
+        S[LC::feet_height + f] = fh;
+        S[LC::cur_max_feet_height + f] = fmaxf(cm, fh);
       }
-      bool contact = S[L.contact_forces + 3 * m.feet_body[f] + 2] > 1.0f;
-      bool nfilt = contact || (S[L.last_contacts + f] != 0.0f);
-      S[L.contact_filt + f] = nfilt ? 1.0f : 0.0f;
-      S[L.last_contacts + f] = contact ? 1.0f : 0.0f;
-      S[L.first_contact + f] = (air > 0.0f && nfilt) ? 1.0f : 0.0f;
-      S[L.feet_air_time + f] = air + c.dt;
+      bool contact = S[LC::contact_forces + 3 * m.feet_body[f] + 2] > 1.0f;
+      bool nfilt = contact || (S[LC::last_contacts + f] != 0.0f);
+      S[LC::contact_filt + f] = nfilt ? 1.0f : 0.0f;
+      S[LC::last_contacts + f] = contact ? 1.0f : 0.0f;
+      S[LC::first_contact + f] = (air > 0.0f && nfilt) ? 1.0f : 0.0f;
+      S[LC::feet_air_time + f] = air + c.dt;
     }
     // :479-493 callback
-    float cmd2 = S[L.commands + 2];
+    float cmd2 = S[LC::commands + 2];
     if (c.heading_command) {
       float fwd[3] = {1.0f, 0.0f, 0.0f}, fw[3];
       pf_quat_apply(q, fwd, fw);
       float heading = atan2f(fw[1], fw[0]);
-      cmd2 = pf_clip(0.5f * pf_wrap_to_pi(S[L.commands + 3] - heading), -1.0f, 1.0f);
+      cmd2 = pf_clip(0.5f * pf_wrap_to_pi(S[LC::commands + 3] - heading), -1.0f, 1.0f);
     }
     bool push = c.push_robots && (step % c.push_interval == 0);
     float ef[3] = {0.0f, 0.0f, 0.0f};
@@ -796,15 +868,15 @@ struct PfKernel {
     }
     PF_SYNC();
     PF_ONE {
-      for (int t = 0; t < 3; ++t) { S[L.base_lin_vel + t] = blv[t]; S[L.base_ang_vel + t] = bav[t]; S[L.projected_gravity + t] = pg[t]; }
-      S[L.commands + 2] = cmd2;
-      if (push) { S[L.ext_force] = ef[0]; S[L.ext_force + 1] = ef[1]; S[L.ext_force + 2] = ef[2]; S[L.ext_force + 3] = 1.0f; }
+      for (int t = 0; t < 3; ++t) { S[LC::base_lin_vel + t] = blv[t]; S[LC::base_ang_vel + t] = bav[t]; S[LC::projected_gravity + t] = pg[t]; }
+      S[LC::commands + 2] = cmd2;
+      if (push) { S[LC::ext_force] = ef[0]; S[LC::ext_force + 1] = ef[1]; S[LC::ext_force + 2] = ef[2]; S[LC::ext_force + 3] = 1.0f; }
     }
     PF_SYNC();
     // :239-247 termination (uniform)
     bool term = false;
     for (int t = 0; t < m.n_term; ++t) {
-      const float* Fc = S + L.contact_forces + 3 * m.term_body[t];
+      const float* Fc = S + LC::contact_forces + 3 * m.term_body[t];
       term = term || (sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1] + Fc[2] * Fc[2]) > 1.0f);
     }
     bool time_out = (float)ep > c.max_episode_length;
@@ -818,47 +890,47 @@ struct PfKernel {
         case PF_REW_ANG_VEL_XY: v = bav[0] * bav[0] + bav[1] * bav[1]; break;
         case PF_REW_ORIENTATION: v = pg[0] * pg[0] + pg[1] * pg[1]; break;
         case PF_REW_BASE_HEIGHT: { float bh = c.measure_heights ? hsum / (float)H : root_z; v = (bh - c.base_height_target) * (bh - c.base_height_target); } break;
-        case PF_REW_TORQUES: for (int k = 0; k < ND; ++k) v += S[L.torques + k] * S[L.torques + k]; break;
-        case PF_REW_DOF_VEL: for (int k = 0; k < ND; ++k) v += S[L.dof_vel + k] * S[L.dof_vel + k]; break;
-        case PF_REW_DOF_ACC: for (int k = 0; k < ND; ++k) { float a = (S[L.last_dof_vel + k] - S[L.dof_vel + k]) / c.dt; v += a * a; } break;
-        case PF_REW_ACTION_RATE: for (int k = 0; k < c.num_actions; ++k) { float a = S[L.last_actions + k] - S[L.actions + k]; v += a * a; } break;
+        case PF_REW_TORQUES: for (int k = 0; k < ND; ++k) v += S[LC::torques + k] * S[LC::torques + k]; break;
+        case PF_REW_DOF_VEL: for (int k = 0; k < ND; ++k) v += S[LC::dof_vel + k] * S[LC::dof_vel + k]; break;
+        case PF_REW_DOF_ACC: for (int k = 0; k < ND; ++k) { float a = (S[LC::last_dof_vel + k] - S[LC::dof_vel + k]) / c.dt; v += a * a; } break;
+        case PF_REW_ACTION_RATE: for (int k = 0; k < c.num_actions; ++k) { float a = S[LC::last_actions + k] - S[LC::actions + k]; v += a * a; } break;
         case PF_REW_COLLISION:
-          for (int t = 0; t < m.n_pen; ++t) { const float* Fc = S + L.contact_forces + 3 * m.pen_body[t]; v += (sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1] + Fc[2] * Fc[2]) > 0.1f) ? 1.0f : 0.0f; }
+          for (int t = 0; t < m.n_pen; ++t) { const float* Fc = S + LC::contact_forces + 3 * m.pen_body[t]; v += (sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1] + Fc[2] * Fc[2]) > 0.1f) ? 1.0f : 0.0f; }
           break;
         case PF_REW_TERMINATION: v = (reset && !time_out) ? 1.0f : 0.0f; break;
         case PF_REW_DOF_POS_LIMITS:
-          for (int k = 0; k < ND; ++k) { float o = -fminf(S[L.dof_pos + k] - c.dof_pos_soft_lo[k], 0.0f); o += fmaxf(S[L.dof_pos + k] - c.dof_pos_soft_hi[k], 0.0f); v += o; }
+          for (int k = 0; k < ND; ++k) { float o = -fminf(S[LC::dof_pos + k] - c.dof_pos_soft_lo[k], 0.0f); o += fmaxf(S[LC::dof_pos + k] - c.dof_pos_soft_hi[k], 0.0f); v += o; }
           break;
-        case PF_REW_DOF_VEL_LIMITS: for (int k = 0; k < ND; ++k) v += pf_clip(fabsf(S[L.dof_vel + k]) - c.dof_vel_limits[k] * c.soft_dof_vel_limit, 0.0f, 1.0f); break;
-        case PF_REW_TORQUE_LIMITS: for (int k = 0; k < ND; ++k) v += fmaxf(fabsf(S[L.torques + k]) - c.torque_limits[k] * c.soft_torque_limit, 0.0f); break;
-        case PF_REW_TRACKING_LIN_VEL: { float ex = S[L.commands] - blv[0], ey = S[L.commands + 1] - blv[1]; v = expf(-(ex * ex + ey * ey) / c.tracking_sigma); } break;
+        case PF_REW_DOF_VEL_LIMITS: for (int k = 0; k < ND; ++k) v += pf_clip(fabsf(S[LC::dof_vel + k]) - c.dof_vel_limits[k] * c.soft_dof_vel_limit, 0.0f, 1.0f); break;
+        case PF_REW_TORQUE_LIMITS: for (int k = 0; k < ND; ++k) v += fmaxf(fabsf(S[LC::torques + k]) - c.torque_limits[k] * c.soft_torque_limit, 0.0f); break;
+        case PF_REW_TRACKING_LIN_VEL: { float ex = S[LC::commands] - blv[0], ey = S[LC::commands + 1] - blv[1]; v = expf(-(ex * ex + ey * ey) / c.tracking_sigma); } break;
         case PF_REW_TRACKING_ANG_VEL: { float e = cmd2 - bav[2]; v = expf(-(e * e) / c.tracking_sigma); } break;
         case PF_REW_FEET_AIR_TIME: {
           float lo = 0.0f, hi = 0.0f;
-          for (int f = 0; f < NF; ++f) { float fc = S[L.first_contact + f], at = S[L.feet_air_time + f]; lo += fminf(at - c.min_feet_air_time, 0.0f) * fc; hi += fminf(c.max_feet_air_time - at, 0.0f) * fc; }
+          for (int f = 0; f < NF; ++f) { float fc = S[LC::first_contact + f], at = S[LC::feet_air_time + f]; lo += fminf(at - c.min_feet_air_time, 0.0f) * fc; hi += fminf(c.max_feet_air_time - at, 0.0f) * fc; }
           v = lo + hi;
         } break;
-        case PF_REW_NO_FLY: { float n = 0.0f; for (int f = 0; f < NF; ++f) n += (S[L.contact_forces + 3 * m.feet_body[f] + 2] > 0.1f) ? 1.0f : 0.0f; v = (n == 1.0f) ? 1.0f : 0.0f; } break;
+        case PF_REW_NO_FLY: { float n = 0.0f; for (int f = 0; f < NF; ++f) n += (S[LC::contact_forces + 3 * m.feet_body[f] + 2] > 0.1f) ? 1.0f : 0.0f; v = (n == 1.0f) ? 1.0f : 0.0f; } break;
         case PF_REW_UNBALANCE_FEET_AIR_TIME:
         case PF_REW_UNBALANCE_FEET_HEIGHT: {
-          const float* a = S + (c.reward_id[ri] == PF_REW_UNBALANCE_FEET_AIR_TIME ? L.last_feet_air_time : L.last_max_feet_height);
+          const float* a = S + (c.reward_id[ri] == PF_REW_UNBALANCE_FEET_AIR_TIME ? LC::last_feet_air_time : LC::last_max_feet_height);
           float mean = 0.0f; for (int f = 0; f < NF; ++f) mean += a[f]; mean /= (float)NF;
           float s = 0.0f; for (int f = 0; f < NF; ++f) s += (a[f] - mean) * (a[f] - mean);
           v = s / (float)(NF - 1);
         } break;
         case PF_REW_STUMBLE:
-          for (int f = 0; f < NF; ++f) { const float* Fc = S + L.contact_forces + 3 * m.feet_body[f]; if (sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1]) > 5.0f * fabsf(Fc[2])) v = 1.0f; }
+          for (int f = 0; f < NF; ++f) { const float* Fc = S + LC::contact_forces + 3 * m.feet_body[f]; if (sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1]) > 5.0f * fabsf(Fc[2])) v = 1.0f; }
           break;
         case PF_REW_STAND_STILL:
-          v = (fabsf(blv[0]) * (S[L.commands] < 0.1f ? 1.0f : 0.0f) + fabsf(blv[1]) * (S[L.commands + 1] < 0.1f ? 1.0f : 0.0f)) + fabsf(bav[2]) * (cmd2 < 0.1f ? 1.0f : 0.0f);
+          v = (fabsf(blv[0]) * (S[LC::commands] < 0.1f ? 1.0f : 0.0f) + fabsf(blv[1]) * (S[LC::commands + 1] < 0.1f ? 1.0f : 0.0f)) + fabsf(bav[2]) * (cmd2 < 0.1f ? 1.0f : 0.0f);
           break;
         case PF_REW_FEET_CONTACT_FORCES:
-          for (int f = 0; f < NF; ++f) { const float* Fc = S + L.contact_forces + 3 * m.feet_body[f]; v += fmaxf(sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1] + Fc[2] * Fc[2]) - c.max_contact_force, 0.0f); }
+          for (int f = 0; f < NF; ++f) { const float* Fc = S + LC::contact_forces + 3 * m.feet_body[f]; v += fmaxf(sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1] + Fc[2] * Fc[2]) - c.max_contact_force, 0.0f); }
           break;
         case PF_REW_FEET_DISTANCE:
           for (int i = 0; i < NF - 1; ++i) {
             int j = NF - 1;
-            float dx = S[L.feet_pos + 3 * i] - S[L.feet_pos + 3 * j], dy = S[L.feet_pos + 3 * i + 1] - S[L.feet_pos + 3 * j + 1];
+            float dx = S[LC::feet_pos + 3 * i] - S[LC::feet_pos + 3 * j], dy = S[LC::feet_pos + 3 * i + 1] - S[LC::feet_pos + 3 * j + 1];
             v += pf_clip(c.min_feet_distance - sqrtf(dx * dx + dy * dy), 0.0f, 1.0f);
           }
           break;
@@ -867,13 +939,13 @@ struct PfKernel {
       }
       float r = v * c.reward_scale[ri];
       rew += r;
-      if (PF_LANE_ID == 0) S[L.episode_sums + ri] += r;
+      if (PF_LANE_ID == 0) S[LC::episode_sums + ri] += r;
     }
     if (c.only_positive_rewards) rew = fmaxf(rew, 0.0f);
     if (c.termination_scale != 0.0f) {
       float r = ((reset && !time_out) ? 1.0f : 0.0f) * c.termination_scale;
       rew += r;
-      if (PF_LANE_ID == 0) S[L.episode_sums + c.num_rewards] += r;
+      if (PF_LANE_ID == 0) S[LC::episode_sums + c.num_rewards] += r;
     }
     PF_ONE {
       B.d_rew[env] = rew; B.d_terminate[env] = term ? 1 : 0; B.d_time_out[env] = time_out ? 1 : 0; B.d_reset[env] = reset ? 1 : 0;
@@ -883,9 +955,9 @@ struct PfKernel {
     if (reset) reset_env(sh, m, c, L, B, inj, env, step);      // :221-222 masked reset
     observations(sh, c, L, B, inj, env, step);                  // :223
     PF_SYNC();
-    PF_LANES(k, c.num_actions) S[L.last_actions + k] = S[L.actions + k];    // :225-227
-    PF_LANES(k, ND) S[L.last_dof_vel + k] = S[L.dof_vel + k];
-    PF_LANES(i, 6) S[L.last_root_vel + i] = S[L.root + 7 + i];
+    PF_LANES(k, c.num_actions) S[LC::last_actions + k] = S[LC::actions + k];    // :225-227
+    PF_LANES(k, ND) S[LC::last_dof_vel + k] = S[LC::dof_vel + k];
+    PF_LANES(i, 6) S[LC::last_root_vel + i] = S[LC::root + 7 + i];
     PF_SYNC();
   }
 };

@@ -21,7 +21,45 @@ from pointfoot_amd.utils.terrain import Terrain
 
 
 class _EpisodeInfo(dict):
-    """extras["episode"]: 0-d device tensors computed without a host sync."""
+    """extras["episode"] (reference :276-285): `rew_<name>` = mean(episode_sums[reset ids]) / max_episode_length_s and
+    `terrain_level`, as 0-d device tensors.  Filled lazily from the step's statistics slot on first access, so a
+    rollout that nobody logs costs no extra kernels and nothing ever synchronises with the host."""
+
+    def __init__(self, fill):
+        super().__init__()
+        self._fill = fill
+
+    def _ensure(self):
+        if self._fill is not None:
+            f, self._fill = self._fill, None
+            super().update(f())
+
+    def __getitem__(self, k):
+        self._ensure(); return super().__getitem__(k)
+
+    def __iter__(self):
+        self._ensure(); return super().__iter__()
+
+    def __len__(self):
+        self._ensure(); return super().__len__()
+
+    def __contains__(self, k):
+        self._ensure(); return super().__contains__(k)
+
+    def keys(self):
+        self._ensure(); return super().keys()
+
+    def items(self):
+        self._ensure(); return super().items()
+
+    def values(self):
+        self._ensure(); return super().values()
+
+    def get(self, k, d=None):
+        self._ensure(); return super().get(k, d)
+
+    def __bool__(self):
+        return True
 
 
 class PointFoot:
@@ -114,6 +152,7 @@ class PointFoot:
         """reference :170-193 — one fused kernel launch."""
         a = actions.detach().to(device=self.device, dtype=torch.float32).contiguous()
         self.common_step_counter += 1
+        self._next_stats_slot()
         _abi.check(self._lib.pf_step(self._h, a.data_ptr(), self.common_step_counter, None, self._stream()), self._lib)
         self._fill_extras()
         return self.proprioceptive_obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
@@ -122,6 +161,7 @@ class PointFoot:
         """parity-test entry: same launch with an injected PfInject (sim snapshot and/or random numbers)."""
         a = actions.detach().to(device=self.device, dtype=torch.float32).contiguous()
         self.common_step_counter += 1
+        self._next_stats_slot()
         _abi.check(self._lib.pf_step(self._h, a.data_ptr(), self.common_step_counter, C.byref(inject), self._stream()), self._lib)
         self._fill_extras()
         return self.proprioceptive_obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
@@ -143,20 +183,27 @@ class PointFoot:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _next_stats_slot(self):
+        """rotate the per-step statistics slot (ring of 64: valid for the iteration the runner logs)"""
+        self._stats_slot = (self._stats_slot + 1) % self._stats_ring.shape[0]
+        self._reset_stats = self._stats_ring[self._stats_slot]
+        _abi.check(self._lib.pf_set_reset_stats(self._h, self._reset_stats.data_ptr()), self._lib)
+
     def _fill_extras(self):
-        # reference :276-288.  rew_<name> = mean(episode_sums[reset ids]) / max_episode_length_s, without syncing
-        stats = self._reset_stats.clone()
-        ep = _EpisodeInfo()
-        cnt = stats[_abi.PF_MAX_REWARDS].clamp(min=1.0)
-        vals = stats[:len(self._sum_names)] / cnt / self.max_episode_length_s
-        for i, k in enumerate(self._sum_names):
-            ep['rew_' + k] = vals[i]
-        if self.cfg.terrain.curriculum:
-            ep["terrain_level"] = torch.mean(self.terrain_levels.float())
-        if self.cfg.commands.curriculum:
-            ep["max_command_x"] = self.command_ranges["lin_vel_x"][1]
-        self.extras["episode"] = ep
-        self.extras["episode_reset_count"] = stats[_abi.PF_MAX_REWARDS]
+        # reference :276-288
+        stats, names, T = self._reset_stats, self._sum_names, self.max_episode_length_s
+        curriculum, levels = self.cfg.terrain.curriculum, self.terrain_levels
+
+        def fill():
+            cnt = stats[_abi.PF_MAX_REWARDS].clamp(min=1.0)
+            vals = stats[:len(names)] / cnt / T
+            ep = {'rew_' + k: vals[i] for i, k in enumerate(names)}
+            if curriculum:
+                ep["terrain_level"] = torch.mean(levels.float())
+            if self.cfg.commands.curriculum:
+                ep["max_command_x"] = self.command_ranges["lin_vel_x"][1]
+            return ep
+        self.extras["episode"] = _EpisodeInfo(fill)
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf
 
@@ -315,7 +362,9 @@ class PointFoot:
         self._episode_length_buf = torch.zeros(N, device=dev, dtype=torch.long)
         H = self._cfg_c.num_height_points
         self.measured_heights = torch.zeros(N, H, device=dev, dtype=torch.float) if H else 0
-        self._reset_stats = torch.zeros(_abi.PF_STATS_FLOATS, device=dev, dtype=torch.float)
+        self._stats_ring = torch.zeros(64, _abi.PF_STATS_FLOATS, device=dev, dtype=torch.float)
+        self._stats_slot = 0
+        self._reset_stats = self._stats_ring[0]
         self.common_step_counter = 0
         self.extras = {}
         self.noise_scale_vec = tuple(None if v is None else torch.tensor(v, device=dev)

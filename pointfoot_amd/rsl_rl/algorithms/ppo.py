@@ -102,6 +102,8 @@ class PPO:
         b.d_returns, b.d_advantages, b.d_log_prob = _ptr(st.returns), _ptr(st.advantages), _ptr(st.actions_log_prob)
         b.d_mu, b.d_sigma, b.d_perm = _ptr(st.mu), _ptr(st.sigma), _ptr(self.perm)
         b.d_workspace, b.workspace_floats, b.d_scalars = _ptr(self.workspace), ws, _ptr(self.scalars)
+        self.ep_return, self.ep_length, self.ep_stats = z(num_envs), z(num_envs), z(4)
+        b.d_ep_return, b.d_ep_length, b.d_ep_stats = _ptr(self.ep_return), _ptr(self.ep_length), _ptr(self.ep_stats)
         self._bufs = b
         _abi.check(lib.ppo_bind_buffers(self._h, C.byref(b)), lib)
         self._actions = torch.zeros(num_envs, c.num_actions, device=dev)

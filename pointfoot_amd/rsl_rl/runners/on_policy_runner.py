@@ -46,9 +46,7 @@ class OnPolicyRunner:
         self.current_learning_iteration = 0
         self.log_interval = int(self.cfg.get("log_interval", 1))
         N, dev = self.env.num_envs, self.device
-        self._cur_reward_sum = torch.zeros(N, dtype=torch.float, device=dev)
-        self._cur_episode_length = torch.zeros(N, dtype=torch.float, device=dev)
-        self._ep_stats = torch.zeros(3, dtype=torch.float, device=dev)       # sum return, sum length, count (since last log)
+        self._ep_stats = self.alg.ep_stats          # [sum return, sum length, count] of finished episodes since the last log
         self.rewbuffer = deque(maxlen=100)
         self.lenbuffer = deque(maxlen=100)
         _, _ = self.env.reset()
@@ -65,19 +63,13 @@ class OnPolicyRunner:
             alg.process_env_step(rewards, dones, infos)
             if self.log_dir is not None and 'episode' in infos:
                 ep_infos.append(infos['episode'])
-            # episode bookkeeping on the device
-            self._cur_reward_sum += rewards
-            self._cur_episode_length += 1
-            d = dones.to(torch.float)
-            self._ep_stats[0] += (self._cur_reward_sum * d).sum()
-            self._ep_stats[1] += (self._cur_episode_length * d).sum()
-            self._ep_stats[2] += d.sum()
-            self._cur_reward_sum *= (1.0 - d)
-            self._cur_episode_length *= (1.0 - d)
+            # (episode return / length bookkeeping happens inside ppo_process_env_step, on the device)
         alg.compute_returns(critic_obs)
         return obs, critic_obs, ep_infos
 
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        if self.log_dir is not None and self.rank == 0:
+            os.makedirs(self.log_dir, exist_ok=True)
         if self.log_dir is not None and self.writer is None and self.rank == 0:
             try:
                 from torch.utils.tensorboard import SummaryWriter
@@ -130,7 +122,7 @@ class OnPolicyRunner:
                 if self.writer:
                     self.writer.add_scalar('Episode/' + key, value, locs['it'])
                 ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
-        mean_std = float(self.alg.actor_critic.std.mean())
+        mean_std = float(self.alg.actor_critic.std.detach().mean())
         fps = int(n_total / iteration_time)
         vl, sl, lr = float(locs['mean_value_loss']), float(locs['mean_surrogate_loss']), float(self.alg.current_learning_rate)
         if self.writer:
