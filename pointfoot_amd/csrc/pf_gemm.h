@@ -167,24 +167,38 @@ static inline void pf_gemm_launch(const GemmArgs& g, int splits, hipStream_t s) 
   hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM>), grid, dim3(256), 0, s, g);
 }
 
-// Tile choice: the fp32 MFMA loop is matrix-pipe bound, so what matters is (a) per-tile efficiency (bigger tiles reuse
-// fragments more) and (b) how evenly the grid fills the 256 CUs (a 384-block grid costs as much as a 512-block one).
-static inline int pf_pick_tile(int M, int N, int splits) {
+// Tile choice from a small cost model calibrated on MI355X (tools/gemm_bench.py): the main loop runs at the matrix
+// pipe's rate (64 cycles per v_mfma_f32_32x32x2_f32 at the ~1.57 GHz the chip sustains on random fp32 data), every block
+// pays a prologue/epilogue cost that grows with its tile (first global->LDS fill, C-tile write with bias/ELU), and the
+// grid runs in ceil(blocks / 256 CUs) rounds.  Returns the modelled time in cycles; `tile_out` = 0: 128x128, 1: 128x64,
+// 2: 64x64.
+static inline float pf_tile_cost(int M, int N, int K, int splits, int t) {
   const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
-  const float eff[3] = {1.0f, 0.92f, 0.78f};
-  int best = 2; float best_score = -1.0f;
-  for (int i = 0; i < 3; ++i) {
-    long blocks = (long)((M + bm[i] - 1) / bm[i]) * ((N + bn[i] - 1) / bn[i]) * (splits > 0 ? splits : 1);
-    long rounds = (blocks + 255) / 256;
-    float useful = (float)M * (float)N / ((float)((M + bm[i] - 1) / bm[i]) * bm[i] * (float)((N + bn[i] - 1) / bn[i]) * bn[i]);
-    float score = eff[i] * useful * (float)blocks / (float)(rounds * 256);
-    if (score > best_score) { best_score = score; best = i; }
-  }
+  const float cyc[3] = {4096.0f, 2048.0f / 0.95f, 1024.0f / 0.90f}, ovh[3] = {30000.0f, 11000.0f, 4200.0f};
+  int S = splits > 0 ? splits : 1;
+  long blocks = (long)((M + bm[t] - 1) / bm[t]) * ((N + bn[t] - 1) / bn[t]) * S;
+  long rounds = (blocks + 255) / 256;
+  int ktiles = ((K + S - 1) / S + 31) / 32;
+  return (float)rounds * ((float)ktiles * cyc[t] + ovh[t]);
+}
+static inline int pf_pick_tile(int M, int N, int K, int splits) {
+  int best = 0; float bc = 1e30f;
+  for (int t = 0; t < 3; ++t) { float c = pf_tile_cost(M, N, K, splits, t); if (c < bc) { bc = c; best = t; } }
   return best;
+}
+// Split-K choice for the weight-gradient GEMM (output only out x in, reduction over tens of thousands of rows): measured
+// on MI355X (tools/gemm_sweep_bwdw.py) the time falls ~1/S until the grid holds ~4 blocks per CU, and 64x64 tiles
+// (most blocks per slab byte) win or tie everywhere, so: 64x64 tiles, S = ~1024 blocks / tiles, capped.
+static inline void pf_pick_split(int M, int N, int K, int max_splits, int* tile_out, int* splits_out) {
+  int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  int S = (1024 + tiles - 1) / tiles;
+  if (S > max_splits) S = max_splits;
+  while (S > 1 && (K + S - 1) / S < 64) --S;
+  *tile_out = 2; *splits_out = S < 1 ? 1 : S;
 }
 template <bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
 static inline void pf_gemm_auto(const GemmArgs& g, int splits, hipStream_t s) {
-  switch (pf_pick_tile(g.M, g.N, splits)) {
+  switch (pf_pick_tile(g.M, g.N, g.K, splits)) {
     case 0: pf_gemm_launch<128, 128, A_KC, B_KC, EPI, COLSUM>(g, splits, s); break;
     case 1: pf_gemm_launch<128, 64, A_KC, B_KC, EPI, COLSUM>(g, splits, s); break;
     default: pf_gemm_launch<64, 64, A_KC, B_KC, EPI, COLSUM>(g, splits, s); break;

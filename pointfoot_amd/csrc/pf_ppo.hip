@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/pointfoot_hip.h"
@@ -402,7 +403,7 @@ static void ppo_plan(PpoAlg* a) {
   for (int i = 0; i < a->actor.nl; ++i) { mw = std::max(mw, a->actor.l[i].out); maxw = std::max(maxw, (size_t)a->actor.l[i].in * a->actor.l[i].out); }
   for (int i = 0; i < a->critic.nl; ++i) { mw = std::max(mw, a->critic.l[i].out); maxw = std::max(maxw, (size_t)a->critic.l[i].in * a->critic.l[i].out); }
   a->max_width = mw;
-  a->splits = 64;
+  a->splits = 128;
   size_t R = a->max_rows, w = 0;
   auto take = [&](size_t n) { size_t at = w; w += (n + 63) & ~(size_t)63; return at; };
   a->w_xa = take(R * c.num_obs); a->w_xc = take(R * c.num_critic_obs); a->w_act = take(R * c.num_actions);
@@ -464,12 +465,14 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
     {
       GemmArgs g{};
       g.A = gcur; g.B = in; g.C = slabs; g.M = L.out; g.N = L.in; g.K = M; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
-      int tiles = ((L.out + 127) / 128) * ((L.in + 127) / 128);
-      int want = std::max(1, std::min(a->splits, 512 / std::max(tiles, 1)));
+      int tile, want;
+      pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
       int per = ((M + want - 1) / want + 31) / 32 * 32;
       int S = (M + per - 1) / per;
       g.k_per_split = per;
-      pf_gemm_auto<false, false, GEMM_EPI_NONE, true>(g, S, s);
+      if (tile == 0) pf_gemm_launch<128, 128, false, false, GEMM_EPI_NONE, true>(g, S, s);
+      else if (tile == 1) pf_gemm_launch<128, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
+      else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
       int nw = L.out * L.in + L.out;
       hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, S, slabs, G + L.w);
     }
@@ -485,6 +488,39 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
 }
 
 extern "C" {
+
+/* Development / test hook (not part of the drop-in boundary, hence not in pointfoot_hip.h): run one GEMM of the PPO
+ * kernel family.  mode 0: C[M,N] = A[M,K] B[N,K]^T + bias, ELU; 1: C[M,N] = A[M,K] B[K,N] * ELU'(H); 2: C[M,N] = A[K,M]^T B[K,N]
+ * (split-K slabs into `ws`, then reduced into C with the column sums of A in C[M*N .. M*N+M)).  tile: -1 auto, 0/1/2. */
+int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, float* Cm, const float* bias, const float* H,
+                 float* ws, int splits, int tile, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = Cm; g.M = M; g.N = N; g.K = K; g.bias = bias; g.H = H; g.ldh = N; g.ldc = N;
+  auto run = [&](auto kc_a, auto kc_b, auto epi, auto cs, int S) {
+    constexpr bool AK = decltype(kc_a)::value, BK_ = decltype(kc_b)::value, CS = decltype(cs)::value;
+    constexpr int E = decltype(epi)::value;
+    int t = tile >= 0 ? tile : pf_pick_tile(M, N, K, S);
+    if (t == 0) pf_gemm_launch<128, 128, AK, BK_, E, CS>(g, S, s);
+    else if (t == 1) pf_gemm_launch<128, 64, AK, BK_, E, CS>(g, S, s);
+    else pf_gemm_launch<64, 64, AK, BK_, E, CS>(g, S, s);
+  };
+  using T = std::true_type; using F = std::false_type;
+  if (mode == 0) { g.lda = K; g.ldb = K; run(T{}, T{}, std::integral_constant<int, GEMM_EPI_BIAS_ELU>{}, F{}, 0); }
+  else if (mode == 1) { g.lda = K; g.ldb = N; run(T{}, F{}, std::integral_constant<int, GEMM_EPI_MUL_DELU>{}, F{}, 0); }
+  else {
+    g.lda = M; g.ldb = N; g.C = ws;
+    int want = splits;
+    if (tile < 0) pf_pick_split(M, N, K, splits, &tile, &want);
+    int per = ((K + want - 1) / want + 31) / 32 * 32, S = (K + per - 1) / per;
+    g.k_per_split = per;
+    run(F{}, F{}, std::integral_constant<int, GEMM_EPI_NONE>{}, T{}, S);
+    int nw = M * N + M;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, S, ws, Cm);
+  }
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
 
 int64_t ppo_num_params(const PpoConfig* cfg) {
   if (ppo_check_cfg(cfg)) return -1;
@@ -527,7 +563,7 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   mlp_forward(a, a->actor, d_obs, N, a->w_ha, s);
   mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s);
   size_t tn = (size_t)t * N;
-  hipLaunchKernelGGL(k_sample, dim3((N + 255) / 256), dim3(256), 0, s, N, A, O, P, d_obs, d_critic_obs, ws + a->w_ha[a->actor.nl - 1],
+  hipLaunchKernelGGL(k_sample, dim3(std::max((N + 255) / 256, 512)), dim3(256), 0, s, N, A, O, P, d_obs, d_critic_obs, ws + a->w_ha[a->actor.nl - 1],
                      ws + a->w_hc[a->critic.nl - 1], a->b.d_params + a->std_off, d_inject_normal, c.seed_lo, c.seed_hi, (uint32_t)sample_counter,
                      0u, d_actions_out, a->b.d_obs + tn * O, a->b.d_critic_obs + tn * P, a->b.d_actions + tn * A, a->b.d_values + tn,
                      a->b.d_log_prob + tn, a->b.d_mu + tn * A, a->b.d_sigma + tn * A);
