@@ -14,7 +14,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { GEMM_EPI_NONE = 0, GEMM_EPI_BIAS = 1, GEMM_EPI_BIAS_ELU = 2, GEMM_EPI_MUL_DELU = 3 };
 
@@ -31,7 +34,7 @@ struct GemmArgs {
 __device__ __forceinline__ float pf_elu(float x) { return x > 0.0f ? x : (__expf(x) - 1.0f); }
 
 // A_KC: A stored [M][K] (k contiguous) else [K][M] (m contiguous).  B_KC: B stored [N][K] else [K][N].
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false, bool MF16 = false>
 __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
   constexpr int BK = 32;
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -107,64 +110,110 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
     }
   };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
   float csum = 0.0f;   // COLSUM: sum over the reduction rows of A[:, m0 + tid] (bias gradient), blocks with blockIdx.x == 0
-  const int arow = wr * (BM / 2) + (lane & 31), bcol = wc * (BN / 2) + (lane & 31), kh = lane >> 5;
-  fetch(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    __syncthreads();          // previous tile fully consumed
-    stage();
-    __syncthreads();
-    if (k0 + BK < k_end) fetch(k0 + BK);
-    if (COLSUM && blockIdx.x == 0 && tid < BM) {
+  auto epilogue_store = [&](int row, int col, float v) {
+    if (row >= g.M || col >= g.N) return;
+    if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) v += g.bias[col];
+    if (EPI == GEMM_EPI_BIAS_ELU) v = pf_elu(v);
+    if (EPI == GEMM_EPI_MUL_DELU) { float h = g.H[(size_t)row * g.ldh + col]; v *= (h > 0.0f ? 1.0f : h + 1.0f); }
+    Cout[(size_t)row * g.ldc + col] = v;
+  };
+  if constexpr (!MF16) {
+    // ---- v_mfma_f32_32x32x2_f32: wave tile = TM x TN tiles of 32x32
+    f32x16 acc[TM][TN];
 #pragma unroll
-      for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDA_S + tid];
-    }
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + kh) * LDA_S + arow + 32 * i];
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int arow = wr * (BM / 2) + (lane & 31), bcol = wc * (BN / 2) + (lane & 31), kh = lane >> 5;
+    fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+      __syncthreads();          // previous tile fully consumed
+      stage();
+      __syncthreads();
+      if (k0 + BK < k_end) fetch(k0 + BK);
+      if (COLSUM && blockIdx.x == 0 && tid < BM) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + kh) * LDB_S + bcol + 32 * j];
+        for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDA_S + tid];
+      }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float a[TM], b[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
-  if (COLSUM && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) Cout[(size_t)g.M * g.ldc + m0 + tid] = csum;
-  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + kh) * LDA_S + arow + 32 * i];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + kh) * LDB_S + bcol + 32 * j];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      int col = n0 + wc * (BN / 2) + 32 * j + (lane & 31);
-      if (col >= g.N) continue;
-      float bv = (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) ? g.bias[col] : 0.0f;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = m0 + wr * (BM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (EPI == GEMM_EPI_BIAS_ELU) v = pf_elu(v);
-        if (EPI == GEMM_EPI_MUL_DELU) { float h = g.H[(size_t)row * g.ldh + col]; v *= (h > 0.0f ? 1.0f : h + 1.0f); }
-        Cout[(size_t)row * g.ldc + col] = v;
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
+    if (COLSUM && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) Cout[(size_t)g.M * g.ldc + m0 + tid] = csum;
+    // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int col = n0 + wc * (BN / 2) + 32 * j + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) epilogue_store(m0 + wr * (BM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col, acc[i][j][r]);
+      }
+  } else {
+    // ---- v_mfma_f32_16x16x4_f32: wave tile = (2 TM) x (2 TN) tiles of 16x16; A[l&15][k=l>>4], B[k=l>>4][l&15]
+    constexpr int UM = 2 * TM, UN = 2 * TN;
+    f32x4 acc[UM][UN];
+#pragma unroll
+    for (int i = 0; i < UM; ++i)
+#pragma unroll
+      for (int j = 0; j < UN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+    const int arow = wr * (BM / 2) + (lane & 15), bcol = wc * (BN / 2) + (lane & 15), kq = lane >> 4;
+    fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+      __syncthreads();
+      stage();
+      __syncthreads();
+      if (k0 + BK < k_end) fetch(k0 + BK);
+      if (COLSUM && blockIdx.x == 0 && tid < BM) {
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDA_S + tid];
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        float a[UM], b[UN];
+#pragma unroll
+        for (int i = 0; i < UM; ++i) a[i] = As[(4 * kk + kq) * LDA_S + arow + 16 * i];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) b[j] = Bs[(4 * kk + kq) * LDB_S + bcol + 16 * j];
+#pragma unroll
+        for (int i = 0; i < UM; ++i)
+#pragma unroll
+          for (int j = 0; j < UN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (COLSUM && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) Cout[(size_t)g.M * g.ldc + m0 + tid] = csum;
+    // C/D layout: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int i = 0; i < UM; ++i)
+#pragma unroll
+      for (int j = 0; j < UN; ++j) {
+        int col = n0 + wc * (BN / 2) + 16 * j + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epilogue_store(m0 + wr * (BM / 2) + 16 * i + (lane >> 4) * 4 + r, col, acc[i][j][r]);
+      }
+  }
 }
 
+static inline bool pf_gemm_use_mf16() { static const bool v = [] { const char* e = getenv("PF_GEMM_MF16"); return e ? atoi(e) != 0 : false; }(); return v; }
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
 static inline void pf_gemm_launch(const GemmArgs& g, int splits, hipStream_t s) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits > 0 ? splits : 1);
-  hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM>), grid, dim3(256), 0, s, g);
+  if (pf_gemm_use_mf16()) hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, false>), grid, dim3(256), 0, s, g);
 }
 
 // Tile choice from a small cost model calibrated on MI355X (tools/gemm_bench.py): the main loop runs at the matrix

@@ -159,26 +159,35 @@ __global__ void k_normalize(size_t n, float* __restrict__ x, float* __restrict__
   if (blockIdx.x == 0 && threadIdx.x == 0) { scalars[SC_ADV_MEAN] = mean; scalars[SC_ADV_STD] = sd; }
 }
 
-// out[i] (+)= sum_s slabs[s][i]
+// out[i] = sum_s slabs[s][i].  Block = 64 consecutive outputs x 4 slab lanes (each lane sums every 4th slab with two
+// independent accumulators), combined through LDS in a fixed order: deterministic, 4x the parallelism of one thread
+// per output and short dependent-load chains.
 __global__ void k_reduce_slabs(int n, int S, const float* __restrict__ slabs, float* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-  int k = 0;
-  for (; k + 3 < S; k += 4) {
-    s0 += slabs[(size_t)k * n + i]; s1 += slabs[(size_t)(k + 1) * n + i];
-    s2 += slabs[(size_t)(k + 2) * n + i]; s3 += slabs[(size_t)(k + 3) * n + i];
+  __shared__ float sm[4][64];
+  int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  int i = blockIdx.x * 64 + col;
+  float a0 = 0.0f, a1 = 0.0f;
+  if (i < n) {
+    int k = sl;
+    for (; k + 4 < S; k += 8) { a0 += slabs[(size_t)k * n + i]; a1 += slabs[(size_t)(k + 4) * n + i]; }
+    for (; k < S; k += 4) a0 += slabs[(size_t)k * n + i];
   }
-  for (; k < S; ++k) s0 += slabs[(size_t)k * n + i];
-  out[i] = (s0 + s1) + (s2 + s3);
+  sm[sl][col] = a0 + a1;
+  __syncthreads();
+  if (sl == 0 && i < n) out[i] = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
 }
 
 // ------------------------------------------------------------------------------------- minibatch gather
-__global__ void k_gather(int B, int cols, const int* __restrict__ perm, const float* __restrict__ src, float* __restrict__ dst) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)B * cols) return;
-  int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
-  dst[i] = src[(size_t)perm[r] * cols + c];
+struct GatherJob { const float* src; float* dst; int cols; };
+struct GatherArgs { GatherJob job[9]; int njobs; };
+// rsl_rl mini_batch_generator: rows perm[b] of every storage array -> contiguous minibatch arrays (one launch)
+__global__ void k_gather(int B, const int* __restrict__ perm, GatherArgs ga) {
+  const GatherJob j = ga.job[blockIdx.y];
+  size_t n = (size_t)B * j.cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int r = (int)(i / j.cols), c = (int)(i - (size_t)r * j.cols);
+    j.dst[i] = j.src[(size_t)perm[r] * j.cols + c];
+  }
 }
 
 // ------------------------------------------------------------------------------------- thin output layers (out <= 8)
@@ -294,15 +303,21 @@ __global__ void k_loss(int B, int A, float clip, float vcoef, float ecoef, int c
 // finish the loss reductions: dL/dstd (incl. the entropy bonus), KL sum + count for the adaptive LR
 __global__ void k_loss_finish(int nb, int A, int B, float ecoef, const float* __restrict__ partial, const float* __restrict__ stdp,
                               float* __restrict__ dstd, float* __restrict__ grads_tail, float* __restrict__ scalars) {
-  int k = threadIdx.x;
-  if (k < A + 4) {
-    float s = 0.0f;
-    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * (A + 4) + k];
-    if (k < A) dstd[k] = s - ecoef / stdp[k];
-    else if (k == A) { grads_tail[0] = s; grads_tail[1] = (float)B; }
-    else if (k == A + 1) scalars[SC_VLOSS] += s / (float)B;
-    else if (k == A + 2) scalars[SC_SLOSS] += s / (float)B;
-    else scalars[SC_ENTROPY] = s / (float)B;
+  // 16 columns x 16 row-lanes: lane (c, r) sums rows r, r+16, ... of column c; fixed-order combine in LDS
+  __shared__ float sm[16][17];
+  int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  float s = 0.0f;
+  if (c < A + 4) for (int b = r; b < nb; b += 16) s += partial[(size_t)b * (A + 4) + c];
+  sm[r][c] = s;
+  __syncthreads();
+  if (r == 0 && c < A + 4) {
+    float t = 0.0f;
+    for (int i = 0; i < 16; ++i) t += sm[i][c];
+    if (c < A) dstd[c] = t - ecoef / stdp[c];
+    else if (c == A) { grads_tail[0] = t; grads_tail[1] = (float)B; }
+    else if (c == A + 1) scalars[SC_VLOSS] += t / (float)B;
+    else if (c == A + 2) scalars[SC_SLOSS] += t / (float)B;
+    else scalars[SC_ENTROPY] = t / (float)B;
   }
 }
 
@@ -317,9 +332,11 @@ __global__ void k_sumsq1(size_t n, const float* __restrict__ g, float scale, flo
 // single thread: adaptive-KL learning rate (rsl_rl PPO.update), clip coefficient, Adam step counter
 __global__ void k_prepare_step(int nb, const float* __restrict__ partial, const float* __restrict__ grads_tail, int adaptive,
                                float desired_kl, float max_grad_norm, float* __restrict__ scalars) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float q = 0.0f;
-  for (int b = 0; b < nb; ++b) q += partial[b];
+  for (int b = threadIdx.x; b < nb; b += 64) q += partial[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float norm = sqrtf(q);
   scalars[SC_GNORM] = norm;
   float coef = max_grad_norm / (norm + 1e-6f);
@@ -455,7 +472,7 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
     hipLaunchKernelGGL((k_thin_bwd<8>), dim3(nblk), dim3(threads), 0, s, M, L.in, L.out, rows_per_block, dHead, ws + w_h[last - 1], P + L.w,
                        gcur, slabs);
     int nw = L.out * L.in + L.out;       // W then b, contiguous in the flat gradient buffer
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, nblk, slabs, G + L.w);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, s, nw, nblk, slabs, G + L.w);
   }
   for (int i = last - 1; i >= 0; --i) {
     const Layer& L = n.l[i];
@@ -474,7 +491,7 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
       else if (tile == 1) pf_gemm_launch<128, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
       else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
       int nw = L.out * L.in + L.out;
-      hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, S, slabs, G + L.w);
+      hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, s, nw, S, slabs, G + L.w);
     }
     if (i > 0) {
       // dZ_{i-1} = (gcur[M,out] * W_i[out,in]) * ELU'(h_{i-1})
@@ -516,7 +533,7 @@ int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, 
     g.k_per_split = per;
     run(F{}, F{}, std::integral_constant<int, GEMM_EPI_NONE>{}, T{}, S);
     int nw = M * N + M;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 255) / 256), dim3(256), 0, s, nw, S, ws, Cm);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, s, nw, S, ws, Cm);
   }
   PPO_HIP_OK(hipGetLastError());
   return 0;
@@ -626,20 +643,23 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
   float* ws = a->b.d_workspace;
   const int B = a->batch, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   const int* perm = a->b.d_perm + (size_t)mb * B;
-  auto gather = [&](const float* src, size_t dst, int cols) {
-    size_t n = (size_t)B * cols;
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, cols, perm, src, ws + dst);
-  };
-  gather(a->b.d_obs, a->w_xa, O); gather(a->b.d_critic_obs, a->w_xc, P); gather(a->b.d_actions, a->w_act, A);
-  gather(a->b.d_log_prob, a->w_oldlogp, 1); gather(a->b.d_mu, a->w_oldmu, A); gather(a->b.d_sigma, a->w_oldsig, A);
-  gather(a->b.d_advantages, a->w_adv, 1); gather(a->b.d_returns, a->w_ret, 1); gather(a->b.d_values, a->w_oldval, 1);
+  {
+    GatherArgs ga;
+    const float* srcs[9] = {a->b.d_obs, a->b.d_critic_obs, a->b.d_actions, a->b.d_log_prob, a->b.d_mu, a->b.d_sigma, a->b.d_advantages,
+                            a->b.d_returns, a->b.d_values};
+    const size_t dsts[9] = {a->w_xa, a->w_xc, a->w_act, a->w_oldlogp, a->w_oldmu, a->w_oldsig, a->w_adv, a->w_ret, a->w_oldval};
+    const int cols[9] = {O, P, A, 1, A, A, 1, 1, 1};
+    for (int i = 0; i < 9; ++i) ga.job[i] = GatherJob{srcs[i], ws + dsts[i], cols[i]};
+    ga.njobs = 9;
+    hipLaunchKernelGGL(k_gather, dim3(240, 9), dim3(256), 0, s, B, perm, ga);
+  }
   mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s);
   mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s);
   const float* stdp = a->b.d_params + a->std_off;
   hipLaunchKernelGGL(k_loss, dim3(RED_BLOCKS), dim3(256), 0, s, B, A, c.clip_param, c.value_loss_coef, c.entropy_coef, c.use_clipped_value_loss,
                      ws + a->w_ha[a->actor.nl - 1], ws + a->w_hc[a->critic.nl - 1], stdp, ws + a->w_act, ws + a->w_oldlogp, ws + a->w_oldmu,
                      ws + a->w_oldsig, ws + a->w_adv, ws + a->w_ret, ws + a->w_oldval, ws + a->w_dmean, ws + a->w_dvalue, ws + a->w_partial);
-  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, s, RED_BLOCKS, A, B, c.entropy_coef, ws + a->w_partial, stdp,
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, RED_BLOCKS, A, B, c.entropy_coef, ws + a->w_partial, stdp,
                      a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
   mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, ws + a->w_dmean, s);
   mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, ws + a->w_dvalue, s);
