@@ -28,6 +28,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
 STEP_BYTES_PER_ENV = 2072      # algorithmic bytes per env-step, pointfoot_rough
 PPO_MFLOP_PER_ENV_STEP = 13.4  # 0.84 rollout + 12.5 update
+# HBM bytes per step-kernel launch from rocprofv3 PMC passes (profiles/r1_step_kernel_hbm_pmc.md; N=4096 rough):
+# FETCH_SIZE 8104 KB (x2: gfx950 half-count correction) + WRITE_SIZE 24345 KB (15 MB of it scratch write-back)
+STEP_TRAFFIC_BYTES_N4096_ROUGH = 2 * 8104.4 * 1024 + 24345.1 * 1024
 
 
 def parse():
@@ -38,6 +41,8 @@ def parse():
     p.add_argument("--num_envs", type=int, default=NUM_ENVS)
     p.add_argument("--task", type=str, default="pointfoot_rough")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    p.add_argument("--single_device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     return p.parse_args()
 
 
@@ -114,9 +119,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.single_device:
+        local = 0
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        dist.init_process_group(a.backend)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
@@ -192,7 +199,8 @@ def main():
                        "parallelism": f"dp{n_gpus} (env shards, RCCL gradient all-reduce)" if n_gpus > 1 else "single GPU",
                        "finite": finite},
             "roofline": {"kernel": "pf_step_kernel<9,6,2> (fused env step)", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                         "traffic": STEP_TRAFFIC_BYTES_N4096_ROUGH if (rough and a.num_envs == 4096) else None,
                          "launch_ms": step_ms, "bytes_per_launch": bytes_per_env * a.num_envs,
                          "note": "latency/occupancy-bound by construction (SURVEY §8d honesty note); launch_ms from HIP events on the launch stream"},
             "roofline_ppo": {"kernel": "pf_gemm_kernel (fp32 MFMA) inside the PPO update", "bound": "mfma", "achieved": ach_tf,

@@ -262,7 +262,9 @@ class PointFoot:
         rm, rc = getattr(dr, "randomize_base_mass", False), getattr(dr, "randomize_base_com", False)
         if rm or rc:
             ncol = (1 if rm else 0) + (3 if rc else 0)
-            u = np.random.uniform(0.0, 1.0, (N, ncol))
+            # single process: numpy's global stream, consumed per env like the reference; shards: a per-rank stream
+            rs = np.random if self.world_size == 1 else np.random.RandomState(int(getattr(self.cfg, "seed", 1)) + 1009 * (self.rank + 1))
+            u = rs.uniform(0.0, 1.0, (N, ncol))
             k = 0
             if rm:
                 a, b = dr.added_mass_range
