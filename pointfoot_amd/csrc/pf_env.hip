@@ -44,6 +44,7 @@ struct PfEnv {
   PfConfig* d_cfg = nullptr;
   int device = 0;
   bool bound = false;
+  unsigned* d_stamps = nullptr;   // diagnostic build (-DPF_STAMPS) only
 };
 
 extern "C" {
@@ -127,6 +128,9 @@ int pf_set_reset_stats(PfEnv* e, float* d_reset_stats) {
   return 0;
 }
 
+/* diagnostic build only: per-env phase cycle counters (PF_NSTAMP unsigned per env); not part of the boundary */
+int pf_debug_set_stamps(PfEnv* e, unsigned* d_stamps) { if (!e) return 1; e->d_stamps = d_stamps; return 0; }
+
 int pf_update_config(PfEnv* e, const PfConfig* cfg) {
   if (!e || !cfg) { pf_set_error("pf_update_config: null argument"); return 1; }
   if (pf_validate(&e->model, cfg)) return 1;
@@ -148,7 +152,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   if (g.inj.d_root && !(g.inj.d_dof_pre && g.inj.d_dof_post && g.inj.d_contact && g.inj.d_feet_pos)) {
     pf_set_error("pf_step: incomplete injected sim state"); return 1;
   }
-  g.actions = d_actions; g.step_counter = step_counter; g.mode = mode;
+  g.actions = d_actions; g.step_counter = step_counter; g.mode = mode; g.stamps = e->d_stamps;
   hipStream_t s = (hipStream_t)stream;
   if (e->bufs.d_reset_stats && mode != 2) PF_HIP_OK(hipMemsetAsync(e->bufs.d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS, s));
   // PF_STEP_WAVES selects the register budget variant (waves per SIMD the kernel is compiled for)

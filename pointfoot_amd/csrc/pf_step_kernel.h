@@ -12,6 +12,8 @@
 
 #define PF_REC_MAX 160
 #define PF_MAXC 6          /* contacts kept per robot (first active in sphere order: feet first) */
+#define PF_MAX_CHAINS 8
+#define PF_MAX_CHAIN_DEPTH 8
 #define PF_KSPH 24         /* collision spheres staged per robot by the kernel instances built so far */
 
 // ------------------------------------------------------------------------------------ small math
@@ -102,6 +104,16 @@ PF_DEV float pf_philox_slot(uint32_t k0, uint32_t k1, uint32_t env, uint32_t ste
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
+// Diagnostic build only (-DPF_STAMPS, tools/step_stamps.py): lane 0 accumulates s_memtime deltas per phase into
+// args.stamps[env][PF_NSTAMP]; the real kernel contains no stamp.
+#define PF_NSTAMP 16
+#if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
+#define PF_STAMP(sh, id) do { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                              (sh).stamp_acc[id] += (unsigned)(t_ - (sh).stamp_last); (sh).stamp_last = t_; } } while (0)
+#else
+#define PF_STAMP(sh, id) ((void)0)
+#endif
+
 struct PfStepArgs {
   const PfModel* model;   // device copy
   const PfConfig* cfg;    // device copy
@@ -111,6 +123,7 @@ struct PfStepArgs {
   const float* actions;
   long long step_counter;
   int mode;               // 0 = step, 1 = reset_idx(all), 2 = compute_observations only
+  unsigned* stamps;       // diagnostic build only, else NULL
 };
 
 template <int NB, int ND, int NF>
@@ -160,10 +173,16 @@ struct PfKernel {
     float q_lo[ND], q_hi[ND], vel_limit[ND];
     int sph_body[PF_KSPH];
     float sph_pos[PF_KSPH][3], sph_radius[PF_KSPH];
+    // root-to-leaf chains (one lane walks one chain in forward kinematics) and per-body 'fixed rotation is identity' flags
+    int nchain, chain_len[PF_MAX_CHAINS], chain[PF_MAX_CHAINS][PF_MAX_CHAIN_DEPTH], rot_ident[NB];
   };
 
   struct Shared {
     ModelS mdl;
+#if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
+    unsigned long long stamp_last;
+    unsigned stamp_acc[PF_NSTAMP];
+#endif
     float rec[PF_REC_MAX];
     float Rw[NB][9], r[NB][3], ax[NB][3];
     float Sj[NB][6], V[NB][6], A[NB][6];      // {ang, lin@O}
@@ -244,69 +263,94 @@ struct PfKernel {
   template <bool WITH_VEL>
   PF_DEV void kinematics(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L) {
     const float* S = sh.rec;
-    int maxdepth = 0;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) maxdepth = m.depth[i] > maxdepth ? m.depth[i] : maxdepth;
-    PF_LANES(i, 1) {
-      const float* q = S + LC::root + 3;
-      float x = q[0], y = q[1], z = q[2], w = q[3];
-      float* R = sh.Rw[0];
-      R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
-      R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
-      R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
-      sh.r[0][0] = 0.0f; sh.r[0][1] = 0.0f; sh.r[0][2] = 0.0f;
+    // base frame / velocity / bias acceleration: uniform (every lane needs them as the root of its chain)
+    float R0[9], V0[6], A0[6];
+    {
+      float x = S[LC::root + 3], y = S[LC::root + 4], z = S[LC::root + 5], w = S[LC::root + 6];
+      R0[0] = 1 - 2 * (y * y + z * z); R0[1] = 2 * (x * y - z * w); R0[2] = 2 * (x * z + y * w);
+      R0[3] = 2 * (x * y + z * w); R0[4] = 1 - 2 * (x * x + z * z); R0[5] = 2 * (y * z - x * w);
+      R0[6] = 2 * (x * z - y * w); R0[7] = 2 * (y * z + x * w); R0[8] = 1 - 2 * (x * x + y * y);
       if (WITH_VEL) {
-        const float* vb = S + LC::root + 7; const float* wb = S + LC::root + 10;
+        float vb[3] = {S[LC::root + 7], S[LC::root + 8], S[LC::root + 9]}, wb[3] = {S[LC::root + 10], S[LC::root + 11], S[LC::root + 12]};
         float wxv[3]; pf_cross(wb, vb, wxv);
-        for (int t = 0; t < 3; ++t) {
-          sh.V[0][t] = wb[t]; sh.V[0][3 + t] = vb[t];
-          sh.A[0][t] = 0.0f; sh.A[0][3 + t] = -wxv[t] - c.gravity[t];
-          sh.Sj[0][t] = 0.0f; sh.Sj[0][3 + t] = 0.0f;
-        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { V0[t] = wb[t]; V0[3 + t] = vb[t]; A0[t] = 0.0f; A0[3 + t] = -wxv[t] - c.gravity[t]; }
       }
     }
-    PF_SYNC();
-    for (int lvl = 1; lvl <= maxdepth; ++lvl) {
-      PF_LANES(i, NB) {
-        if (m.depth[i] != lvl) continue;
-        int p = m.parent[i];
-        float Rj[9]; pf_mat_mul(sh.Rw[p], m.joint_rot[i], Rj);
-        float rp[3]; pf_mat_vec(sh.Rw[p], m.joint_pos[i], rp);
-        float ri[3] = {sh.r[p][0] + rp[0], sh.r[p][1] + rp[1], sh.r[p][2] + rp[2]};
+    PF_ONE {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) sh.Rw[0][t] = R0[t];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { sh.r[0][t] = 0.0f; sh.ax[0][t] = 0.0f; }
+      if (WITH_VEL) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { sh.V[0][t] = V0[t]; sh.A[0][t] = A0[t]; sh.Sj[0][t] = 0.0f; }
+      }
+    }
+    // one lane per root-to-leaf chain: the parent's frame stays in registers, no barrier between tree levels
+    PF_LANES(ch, m.nchain) {
+      float Rp[9], rp[3] = {0.0f, 0.0f, 0.0f}, Vp[6], Ap[6];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) Rp[t] = R0[t];
+      if (WITH_VEL) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { Vp[t] = V0[t]; Ap[t] = A0[t]; }
+      }
+      const int len = m.chain_len[ch];
+      for (int d = 0; d < len; ++d) {
+        const int i = m.chain[ch][d];
+        float Rj[9];
+        if (m.rot_ident[i]) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) Rj[t] = Rp[t];
+        } else pf_mat_mul(Rp, m.joint_rot[i], Rj);
+        float jp[3] = {m.joint_pos[i][0], m.joint_pos[i][1], m.joint_pos[i][2]}, ro[3];
+        pf_mat_vec(Rp, jp, ro);
+        float ri[3] = {rp[0] + ro[0], rp[1] + ro[1], rp[2] + ro[2]};
         sh.r[i][0] = ri[0]; sh.r[i][1] = ri[1]; sh.r[i][2] = ri[2];
-        int k = m.dof_of_body[i];
+        const int k = m.dof_of_body[i];
         if (k >= 0) {
-          const float* a = m.joint_axis[i];
+          float a[3] = {m.joint_axis[i][0], m.joint_axis[i][1], m.joint_axis[i][2]};
           float aw[3]; pf_mat_vec(Rj, a, aw);
           float th = S[LC::dof_pos + k];
           float cs = cosf(th), sn = sinf(th), t1 = 1.0f - cs;
           float Ra[9] = {t1 * a[0] * a[0] + cs, t1 * a[0] * a[1] - sn * a[2], t1 * a[0] * a[2] + sn * a[1],
                          t1 * a[0] * a[1] + sn * a[2], t1 * a[1] * a[1] + cs, t1 * a[1] * a[2] - sn * a[0],
                          t1 * a[0] * a[2] - sn * a[1], t1 * a[1] * a[2] + sn * a[0], t1 * a[2] * a[2] + cs};
-          pf_mat_mul(Rj, Ra, sh.Rw[i]);
+          pf_mat_mul(Rj, Ra, Rp);
           sh.ax[i][0] = aw[0]; sh.ax[i][1] = aw[1]; sh.ax[i][2] = aw[2];
           if (WITH_VEL) {
             float sl[3]; pf_cross(ri, aw, sl);
             float qd = S[LC::dof_vel + k];
             float Vi[6];
-            for (int t = 0; t < 3; ++t) { sh.Sj[i][t] = aw[t]; sh.Sj[i][3 + t] = sl[t]; Vi[t] = sh.V[p][t] + qd * aw[t]; Vi[3 + t] = sh.V[p][3 + t] + qd * sl[t]; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { sh.Sj[i][t] = aw[t]; sh.Sj[i][3 + t] = sl[t]; Vi[t] = Vp[t] + qd * aw[t]; Vi[3 + t] = Vp[3 + t] + qd * sl[t]; }
             float ca[3], c1[3], c2[3];
             pf_cross(Vi, aw, ca); pf_cross(Vi, sl, c1); pf_cross(Vi + 3, aw, c2);
-            for (int t = 0; t < 3; ++t) {
-              sh.V[i][t] = Vi[t]; sh.V[i][3 + t] = Vi[3 + t];
-              sh.A[i][t] = sh.A[p][t] + qd * ca[t];
-              sh.A[i][3 + t] = sh.A[p][3 + t] + qd * (c1[t] + c2[t]);
-            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { Ap[t] += qd * ca[t]; Ap[3 + t] += qd * (c1[t] + c2[t]); }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) Vp[t] = Vi[t];
           }
         } else {
-          for (int t = 0; t < 9; ++t) sh.Rw[i][t] = Rj[t];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) Rp[t] = Rj[t];
           sh.ax[i][0] = 0.0f; sh.ax[i][1] = 0.0f; sh.ax[i][2] = 0.0f;
-          if (WITH_VEL)
-            for (int t = 0; t < 6; ++t) { sh.Sj[i][t] = 0.0f; sh.V[i][t] = sh.V[p][t]; sh.A[i][t] = sh.A[p][t]; }
+          if (WITH_VEL) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) sh.Sj[i][t] = 0.0f;
+          }
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) sh.Rw[i][t] = Rp[t];
+        if (WITH_VEL) {
+#pragma unroll
+          for (int t = 0; t < 6; ++t) { sh.V[i][t] = Vp[t]; sh.A[i][t] = Ap[t]; }
+        }
+        rp[0] = ri[0]; rp[1] = ri[1]; rp[2] = ri[2];
       }
-      PF_SYNC();
     }
+    PF_SYNC();
   }
 
   // ------------------------------------------------------------------ one physics substep of sim_dt
@@ -314,6 +358,7 @@ struct PfKernel {
     float* S = sh.rec;
     const float dt = c.sim_dt;
     kinematics<true>(sh, m, c, L);
+    PF_STAMP(sh, 1);
     // ---- per-body spatial inertia about O and bias wrench
     PF_LANES(i, NB) {
       float mass = m.mass[i];
@@ -354,18 +399,13 @@ struct PfKernel {
         for (int t = 0; t < 3; ++t) sh.f[0][3 + t] -= S[LC::ext_force + t];
     }
     PF_SYNC();
-    // ---- composites over DFS-contiguous subtrees
-    PF_LANES(i, NB) {
-      float Ic[10], fc[6];
-      for (int t = 0; t < 10; ++t) Ic[t] = sh.I[i][t];
-      for (int t = 0; t < 6; ++t) fc[t] = sh.f[i][t];
+    // ---- composites over DFS-contiguous subtrees: one lane per (body, component)
+    PF_LANES(e, NB * 16) {
+      int i = e >> 4, t = e & 15;
       int end = i + m.subtree[i];
-      for (int j = i + 1; j < end; ++j) {
-        for (int t = 0; t < 10; ++t) Ic[t] += sh.I[j][t];
-        for (int t = 0; t < 6; ++t) fc[t] += sh.f[j][t];
-      }
-      for (int t = 0; t < 10; ++t) sh.Ic[i][t] = Ic[t];
-      for (int t = 0; t < 6; ++t) sh.fc[i][t] = fc[t];
+      float acc = 0.0f;
+      if (t < 10) { for (int j = i; j < end; ++j) acc += sh.I[j][t]; sh.Ic[i][t] = acc; }
+      else { for (int j = i; j < end; ++j) acc += sh.f[j][t - 10]; sh.fc[i][t - 10] = acc; }
     }
     PF_SYNC();
     PF_LANES(k, ND) {
@@ -377,6 +417,7 @@ struct PfKernel {
       for (int t = 0; t < 6; ++t) sh.F[k][t] = Fo[t];
     }
     PF_SYNC();
+    PF_STAMP(sh, 2);
     // ---- mass matrix (lower triangle; generalised velocity [v_O, w, qd]) + bias + old velocity
     PF_LANES(e, NV * NV) {
       int a = e / NV, b = e - a * NV;
@@ -420,6 +461,7 @@ struct PfKernel {
       sh.J[RFREE][a] = rhs; sh.W[RFREE][a] = rhs;
     }
     PF_SYNC();
+    PF_STAMP(sh, 3);
     // ---- in-place Cholesky, one column per phase
     for (int j = 0; j < NV; ++j) {
       float d = sh.M[j][j];
@@ -435,6 +477,7 @@ struct PfKernel {
       PF_ONE { sh.dinv[j] = di; }
       PF_SYNC();
     }
+    PF_STAMP(sh, 4);
     // ---- contact candidates: every collision sphere against the terrain
     const int16_t* hs = B.d_height_samples;
     PF_LANES(s, m.nsph) {
@@ -460,6 +503,7 @@ struct PfKernel {
       if (idx < MAXC) { sh.con_sph[idx] = s; sh.cbody[idx] = m.sph_body[s]; }
     }
     PF_SYNC();
+    PF_STAMP(sh, 5);
     // ---- contact rows: Jacobians, targets, then W = M^-1 J^T (one lane per row; + the free-acceleration row)
     const float rest = 0.5f * c.terrain_restitution;
     PF_LANES(rr, 3 * ncon) {
@@ -502,8 +546,10 @@ struct PfKernel {
       sh.rb[rr] = bn; sh.lam[rr] = 0.0f;
     }
     PF_SYNC();
+    PF_STAMP(sh, 6);
     solve_rows(sh, 3 * ncon, true);
     PF_SYNC();
+    PF_STAMP(sh, 7);
     // ---- free velocity
     PF_LANES(a, NV) sh.vel[a] = sh.vold[a] + dt * sh.W[RFREE][a];
     PF_SYNC();
@@ -534,6 +580,7 @@ struct PfKernel {
     PF_SYNC();
     solve_rows_range(sh, CROWS, nlim);
     PF_SYNC();
+    PF_STAMP(sh, 8);
     // ---- per-contact 3x3 Delassus blocks
     PF_LANES(e, ncon * 9) {
       int ci = e / 9, ab = e - 9 * ci, a = ab / 3, b = ab - 3 * a;
@@ -542,42 +589,60 @@ struct PfKernel {
       sh.cA[ci][ab] = s;
     }
     PF_SYNC();
+    PF_STAMP(sh, 9);
     // ---- projected Gauss-Seidel (uniform impulse math, lane-parallel velocity update)
+    // Every lane runs the whole sweep redundantly with the velocity in registers (static indices); impulses live in LDS
+    // and are stored by all lanes with the same value (each lane later re-reads what it wrote), so the dependent
+    // updates need no barrier; J and W rows are LDS broadcast reads.
     const float mu = 0.5f * (S[LC::friction] + c.terrain_friction);
-    for (int it = 0; it < c.solver_iterations; ++it) {
-      for (int ci = 0; ci < ncon; ++ci) {
-        int r0 = 3 * ci;
-        float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
-        for (int t = 0; t < NV; ++t) { float v = sh.vel[t]; u0 += sh.J[r0][t] * v; u1 += sh.J[r0 + 1][t] * v; u2 += sh.J[r0 + 2][t] * v; }
-        float l0 = sh.lam[r0], l1o = sh.lam[r0 + 1], l2o = sh.lam[r0 + 2];
-        float ln = fmaxf(0.0f, l0 + (sh.rb[r0] - u0) * sh.rAinv[r0]);
-        float d0 = ln - l0;
-        float u1c = u1 + sh.cA[ci][3] * d0;
-        float l1 = l1o - u1c * sh.rAinv[r0 + 1];
-        float d1p = l1 - l1o;
-        float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
-        float l2 = l2o - u2c * sh.rAinv[r0 + 2];
-        float lim = mu * ln, nt = sqrtf(l1 * l1 + l2 * l2);
-        if (nt > lim) { float sc = nt > 0.0f ? lim / nt : 0.0f; l1 *= sc; l2 *= sc; }
-        float d1 = l1 - l1o, d2 = l2 - l2o;
-        PF_SYNC();   // all lanes have read vel / lam before anyone overwrites them
-        PF_LANES(t, NV) sh.vel[t] += sh.W[r0][t] * d0 + sh.W[r0 + 1][t] * d1 + sh.W[r0 + 2][t] * d2;
-        PF_ONE { sh.lam[r0] = ln; sh.lam[r0 + 1] = l1; sh.lam[r0 + 2] = l2; }
-        PF_SYNC();
+    {
+      float v[NV];
+#pragma unroll
+      for (int t = 0; t < NV; ++t) v[t] = sh.vel[t];
+      for (int it = 0; it < c.solver_iterations; ++it) {
+#pragma unroll 1
+        for (int ci = 0; ci < ncon; ++ci) {
+          const int r0 = 3 * ci;
+          float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
+#pragma unroll
+          for (int t = 0; t < NV; ++t) { u0 += sh.J[r0][t] * v[t]; u1 += sh.J[r0 + 1][t] * v[t]; u2 += sh.J[r0 + 2][t] * v[t]; }
+          float l0 = sh.lam[r0], l1o = sh.lam[r0 + 1], l2o = sh.lam[r0 + 2];
+          float ln = fmaxf(0.0f, l0 + (sh.rb[r0] - u0) * sh.rAinv[r0]);
+          float d0 = ln - l0;
+          float u1c = u1 + sh.cA[ci][3] * d0;
+          float l1 = l1o - u1c * sh.rAinv[r0 + 1];
+          float d1p = l1 - l1o;
+          float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
+          float l2 = l2o - u2c * sh.rAinv[r0 + 2];
+          float lim = mu * ln, nt = sqrtf(l1 * l1 + l2 * l2);
+          if (nt > lim) { float sc = nt > 0.0f ? lim / nt : 0.0f; l1 *= sc; l2 *= sc; }
+          float d1 = l1 - l1o, d2 = l2 - l2o;
+#pragma unroll
+          for (int t = 0; t < NV; ++t) v[t] += sh.W[r0][t] * d0 + sh.W[r0 + 1][t] * d1 + sh.W[r0 + 2][t] * d2;
+          sh.lam[r0] = ln; sh.lam[r0 + 1] = l1; sh.lam[r0 + 2] = l2;
+        }
+#pragma unroll 1
+        for (int li = 0; li < nlim; ++li) {
+          const int rr = CROWS + li;
+          float u = 0.0f;
+#pragma unroll
+          for (int t = 0; t < NV; ++t) u += sh.J[rr][t] * v[t];
+          float lo = sh.lam[rr];
+          float ln = fmaxf(0.0f, lo + (sh.rb[rr] - u) * sh.rAinv[rr]);
+          float d = ln - lo;
+#pragma unroll
+          for (int t = 0; t < NV; ++t) v[t] += sh.W[rr][t] * d;
+          sh.lam[rr] = ln;
+        }
       }
-      for (int li = 0; li < nlim; ++li) {
-        int rr = CROWS + li;
-        float u = 0.0f;
-        for (int t = 0; t < NV; ++t) u += sh.J[rr][t] * sh.vel[t];
-        float lo = sh.lam[rr];
-        float ln = fmaxf(0.0f, lo + (sh.rb[rr] - u) * sh.rAinv[rr]);
-        float d = ln - lo;
-        PF_SYNC();
-        PF_LANES(t, NV) sh.vel[t] += sh.W[rr][t] * d;
-        PF_ONE { sh.lam[rr] = ln; }
-        PF_SYNC();
+      PF_SYNC();
+      PF_ONE {
+#pragma unroll
+        for (int t = 0; t < NV; ++t) sh.vel[t] = v[t];
       }
+      PF_SYNC();
     }
+    PF_STAMP(sh, 10);
     // ---- integrate (semi-implicit Euler), net contact force per body
     PF_LANES(k, ND) {
       float vl = m.vel_limit[k];
@@ -616,6 +681,7 @@ struct PfKernel {
       }
     }
     PF_SYNC();
+    PF_STAMP(sh, 11);
   }
 
   // W[row] <- M^-1 J[row]^T by forward/back substitution on the in-place Cholesky factor; Ainv = 1/(J.W)
@@ -731,6 +797,9 @@ struct PfKernel {
   PF_DEV void run(Shared& sh, const PfStepArgs& g, int env) {
     const PfModel& gm = *g.model; const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
     ModelS& ms = sh.mdl;
+#if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
+    if (threadIdx.x == 0) { sh.stamp_last = __builtin_amdgcn_s_memtime(); for (int t = 0; t < PF_NSTAMP; ++t) sh.stamp_acc[t] = 0; }
+#endif
     PF_LANES(i, NB) {
       ms.parent[i] = gm.parent[i]; ms.depth[i] = gm.depth[i]; ms.subtree[i] = gm.subtree[i]; ms.dof_of_body[i] = gm.dof_of_body[i];
       ms.mass[i] = gm.mass[i];
@@ -749,9 +818,32 @@ struct PfKernel {
     PF_ONE { ms.nsph = gm.nsph; ms.n_term = gm.n_term; ms.n_pen = gm.n_pen; }
     const ModelS& m = ms;
     float* S = sh.rec;
+    bool need_chains = true;
     float* grow = B.d_state + (size_t)env * L.rec_floats;
     PF_LANES(i, L.rec_floats) S[i] = grow[i];
     PF_SYNC();
+    if (need_chains) {
+      // chains: one per leaf body (subtree == 1); chain[c] lists the bodies from the base's child down to the leaf
+      PF_LANES(b, NB) {
+        bool ident = true;
+        for (int t = 0; t < 9; ++t) ident = ident && (ms.joint_rot[b][t] == ((t % 4 == 0) ? 1.0f : 0.0f));
+        ms.rot_ident[b] = ident ? 1 : 0;
+        if (b > 0 && ms.subtree[b] == 1) {
+          int ci = 0;
+          for (int j = 1; j < b; ++j) ci += ms.subtree[j] == 1 ? 1 : 0;
+          int d = ms.depth[b];
+          if (ci < PF_MAX_CHAINS && d <= PF_MAX_CHAIN_DEPTH) {
+            ms.chain_len[ci] = d;
+            int j = b;
+            for (int kk = d - 1; kk >= 0; --kk) { ms.chain[ci][kk] = j; j = ms.parent[j]; }
+          }
+        }
+      }
+      int nch = 0;
+      for (int j = 1; j < NB; ++j) nch += ms.subtree[j] == 1 ? 1 : 0;
+      PF_ONE { ms.nchain = nch < PF_MAX_CHAINS ? nch : PF_MAX_CHAINS; }
+      PF_SYNC();
+    }
     if (g.mode == 1) {
       reset_env(sh, m, c, L, B, inj, env, g.step_counter);
       PF_ONE { B.d_episode_length[env] = 0; B.d_reset[env] = 1; }
@@ -777,7 +869,9 @@ struct PfKernel {
       PF_SYNC();
     } else {
       for (int sub = 0; sub < c.decimation; ++sub) {     // :180-185
+        PF_STAMP(sh, 0);
         torques(sh, c, L, S + LC::dof_pos, 1, LC::dof_vel - LC::dof_pos);
+        PF_STAMP(sh, 12);
         bool ext = sub == 0 && S[LC::ext_force + 3] != 0.0f;
         substep(sh, m, c, L, B, ext);
         if (ext) { PF_ONE { S[LC::ext_force + 3] = 0.0f; } PF_SYNC(); }
@@ -786,8 +880,15 @@ struct PfKernel {
       PF_LANES(e, NF * 3) { int f = e / 3, t = e - 3 * f; S[LC::feet_pos + e] = S[LC::root + t] + sh.r[m.feet_body[f]][t]; }
       PF_SYNC();
     }
+    PF_STAMP(sh, 13);
     post_physics(sh, m, c, L, B, inj, env, g.step_counter);
+    PF_STAMP(sh, 14);
     PF_LANES(i, L.rec_floats) grow[i] = S[i];
+    PF_SYNC();
+    PF_STAMP(sh, 15);
+#if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
+    if (g.stamps && threadIdx.x == 0) for (int t = 0; t < PF_NSTAMP; ++t) g.stamps[(size_t)env * PF_NSTAMP + t] = sh.stamp_acc[t];
+#endif
   }
 
   // ------------------------------------------------------------------ post_physics_step (:195-230)

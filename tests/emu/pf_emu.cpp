@@ -13,7 +13,7 @@ extern "C" int pfe_step(const PfModel* model, const PfConfig* cfg, const PfLayou
   PfStepArgs g;
   g.model = model; g.cfg = cfg; g.L = *layout; g.b = *bufs;
   if (inject) g.inj = *inject; else std::memset(&g.inj, 0, sizeof(g.inj));
-  g.actions = actions; g.step_counter = step_counter; g.mode = mode;
+  g.actions = actions; g.step_counter = step_counter; g.mode = mode; g.stamps = nullptr;
   if (bufs->d_reset_stats && mode != 2) std::memset(bufs->d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS);
   for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, g, env);
   return 0;
