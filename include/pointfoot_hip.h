@@ -33,11 +33,26 @@ extern "C" {
 #define PF_MAX_FEET 4
 #define PF_MAX_SPHERES 32
 #define PF_MAX_REWARDS 32
-#define PF_MAX_OBS 64
+#define PF_MAX_OBS 256
 #define PF_MAX_HPTS 192
 #define PF_MAX_TERM 8
 #define PF_MAX_PEN 20
 #define PF_STATS_FLOATS (PF_MAX_REWARDS + 4)
+/* actuator network `LSTMsea` (resources/actuator_nets/anydrive_v3_lstm.pt): in_scale(2), out_scale(1), LSTM(2->8) x 2 layers
+ * (PyTorch gate order i,f,g,o), Linear(8->1).  Flat parameter block handed over in d_actuator_params: */
+#define PF_ACT_IN_SCALE 0
+#define PF_ACT_OUT_SCALE 2
+#define PF_ACT_W_IH0 3      /* [32][2] */
+#define PF_ACT_W_HH0 67     /* [32][8] */
+#define PF_ACT_B_IH0 323    /* [32] */
+#define PF_ACT_B_HH0 355
+#define PF_ACT_W_IH1 387    /* [32][8] */
+#define PF_ACT_W_HH1 643
+#define PF_ACT_B_IH1 899
+#define PF_ACT_B_HH1 931
+#define PF_ACT_W_LIN 963    /* [8] */
+#define PF_ACT_B_LIN 971
+#define PF_ACT_PARAMS 972
 
 /* reward term ids — one per `_reward_*` method of point_foot.py:1132-1253 */
 enum PfReward {
@@ -68,6 +83,7 @@ enum PfReward {
   PF_REW_COUNT
 };
 
+enum PfEnvKind { PF_KIND_POINTFOOT = 0 /* envs/pointfoot/point_foot.py */, PF_KIND_LEGGED_ROBOT = 1 /* envs/base/legged_robot.py (+ anymal.py) */ };
 enum PfControl { PF_CTRL_P = 0, PF_CTRL_V = 1, PF_CTRL_T = 2 };      /* point_foot.py:536-546 */
 enum PfTerrain { PF_TERRAIN_PLANE = 0, PF_TERRAIN_HEIGHTFIELD = 1 }; /* point_foot.py:390-400 (trimesh is served by the height field) */
 
@@ -154,6 +170,12 @@ typedef struct PfConfig {
   float contact_offset, bounce_threshold, max_depenetration_vel;
   int32_t solver_iterations;
   uint32_t seed_lo, seed_hi;     /* Philox key */
+  /* LeggedRobot variant (legged_gym/envs/base/legged_robot.py, anymal_c/anymal.py) */
+  int32_t env_kind;              /* PfEnvKind */
+  int32_t resample_interval;     /* int(resampling_time / dt)        legged_robot.py:323 */
+  int32_t use_actuator_net;      /* cfg.control.use_actuator_network anymal.py:71-78 */
+  float cmd_lo[4], cmd_hi[4];    /* ranges: lin_vel_x, lin_vel_y, ang_vel_yaw, heading   legged_robot.py:343-349 */
+  float max_push_vel;            /* cfg.domain_rand.max_push_vel_xy  legged_robot.py:417 */
 } PfConfig;
 
 /* Per-env state record: one contiguous row of `rec_floats` floats per env (AoS: a wavefront owns
@@ -166,9 +188,11 @@ typedef struct PfLayout {
   int32_t contact_filt, first_contact, last_contacts;   /* 0/1 as float */
   int32_t contact_forces, feet_pos, ext_force /* xyz + pending flag */, env_origin;
   int32_t friction, added_mass, added_com;
+  int32_t lstm_state;            /* LeggedRobot: actuator-net h/c, [joint][layer][h(8) c(8)] */
   int32_t episode_sums;
   int32_t rand_floats;           /* width of one row of the injected-random buffer */
   int32_t r_obs, r_priv, r_dof, r_xy, r_vel, r_level, r_push;   /* offsets inside that row */
+  int32_t r_cmd, r_cmd_reset;    /* LeggedRobot command resampling: periodic / at reset (3 draws each) */
 } PfLayout;
 
 /* Device buffers owned by the caller. */
@@ -186,6 +210,7 @@ typedef struct PfBuffers {
   float* d_measured_heights;   /* (N, H) or NULL */
   const int16_t* d_height_samples; /* (hf_rows, hf_cols) or NULL on a plane  :849,867 */
   const float* d_terrain_origins;  /* (max_terrain_level, terrain_num_cols, 3) or NULL */
+  const float* d_actuator_params; /* LeggedRobot + actuator net: PF_ACT_PARAMS floats (see PF_ACT_* offsets) or NULL */
   float* d_reset_stats;        /* (PF_STATS_FLOATS,): [i] = sum of episode_sums[i] over the envs reset this step
                                   (point_foot.py:276-280), [PF_MAX_REWARDS] = number of envs reset; zeroed by pf_step */
 } PfBuffers;

@@ -101,6 +101,52 @@ inline float rnd(const Ctx& x, int env, int slot) {
                        (uint32_t)x.step_counter, 0u, (uint32_t)slot);
 }
 
+// ------------------------------------------------------------------------------------- LeggedRobot helpers
+// legged_robot.py:337-351 _resample_commands for one env; `slot` = first of 3 random slots
+void resample_commands(const Ctx& x, int env, float* S, int slot) {
+  const PfConfig& c = *x.c; const PfLayout& L = *x.L;
+  float cx = (c.cmd_hi[0] - c.cmd_lo[0]) * rnd(x, env, slot) + c.cmd_lo[0];
+  float cy = (c.cmd_hi[1] - c.cmd_lo[1]) * rnd(x, env, slot + 1) + c.cmd_lo[1];
+  int k = c.heading_command ? 3 : 2;
+  float cz = (c.cmd_hi[k] - c.cmd_lo[k]) * rnd(x, env, slot + 2) + c.cmd_lo[k];
+  float keep = std::sqrt(cx * cx + cy * cy) > 0.2f ? 1.0f : 0.0f;
+  S[L.commands] = cx * keep; S[L.commands + 1] = cy * keep; S[L.commands + k] = cz;
+}
+// anymal.py:71-78 actuator network (LSTMsea: in_scale -> LSTM(2->8)x2 -> Linear(8->1) -> out_scale), one time step per joint
+inline float sigm(float v) { return 1.0f / (1.0f + std::exp(-v)); }
+void actuator_torques(const Ctx& x, float* S) {
+  const PfConfig& c = *x.c; const PfLayout& L = *x.L; const int nd = x.m->nd;
+  const float* P = x.b->d_actuator_params;
+  for (int j = 0; j < nd; ++j) {
+    float* st = S + L.lstm_state + j * 32;
+    float x0 = ((S[L.actions + j] * c.action_scale + c.default_dof_pos[j]) - S[L.dof_pos + j]) * P[PF_ACT_IN_SCALE];
+    float x1 = S[L.dof_vel + j] * P[PF_ACT_IN_SCALE + 1];
+    for (int layer = 0; layer < 2; ++layer) {
+      float G[32];
+      for (int g = 0; g < 32; ++g) {
+        float acc;
+        if (layer == 0) {
+          acc = P[PF_ACT_B_IH0 + g] + P[PF_ACT_B_HH0 + g] + P[PF_ACT_W_IH0 + 2 * g] * x0 + P[PF_ACT_W_IH0 + 2 * g + 1] * x1;
+          for (int t = 0; t < 8; ++t) acc += P[PF_ACT_W_HH0 + 8 * g + t] * st[t];
+        } else {
+          acc = P[PF_ACT_B_IH1 + g] + P[PF_ACT_B_HH1 + g];
+          for (int t = 0; t < 8; ++t) acc += P[PF_ACT_W_IH1 + 8 * g + t] * st[t] + P[PF_ACT_W_HH1 + 8 * g + t] * st[16 + t];
+        }
+        G[g] = acc;
+      }
+      float* s2 = st + layer * 16;
+      for (int u = 0; u < 8; ++u) {
+        float ig = sigm(G[u]), fg = sigm(G[8 + u]), gg = std::tanh(G[16 + u]), og = sigm(G[24 + u]);
+        float cn = fg * s2[8 + u] + ig * gg;
+        s2[8 + u] = cn; s2[u] = og * std::tanh(cn);
+      }
+    }
+    float y = P[PF_ACT_B_LIN];
+    for (int t = 0; t < 8; ++t) y += P[PF_ACT_W_LIN + t] * st[16 + t];
+    S[L.torques + j] = y * P[PF_ACT_OUT_SCALE];
+  }
+}
+
 // ------------------------------------------------------------------------------------- PD torques
 // point_foot.py:523-547 _compute_torques
 void compute_torques(const Ctx& x, float* S, const float* qpos, const float* qvel) {
@@ -504,6 +550,26 @@ void feet_positions(const Ctx& x, float* S) {
 void compute_observations(const Ctx& x, int env, float* S, const float* heights) {
   const PfModel& m = *x.m; const PfConfig& c = *x.c; const PfLayout& L = *x.L;
   const int nd = m.nd, na = c.num_actions, no = c.num_obs, np_ = c.num_priv_obs;
+  if (c.env_kind == PF_KIND_LEGGED_ROBOT) {     // legged_robot.py:209-226
+    float* obs = x.b->d_obs + (size_t)env * no;
+    int w = 0;
+    float v[PF_MAX_OBS];
+    for (int i = 0; i < 3; ++i) v[w++] = S[L.base_lin_vel + i] * c.obs_scale_lin_vel;
+    for (int i = 0; i < 3; ++i) v[w++] = S[L.base_ang_vel + i] * c.obs_scale_ang_vel;
+    for (int i = 0; i < 3; ++i) v[w++] = S[L.projected_gravity + i];
+    for (int i = 0; i < 3; ++i) v[w++] = S[L.commands + i] * c.commands_scale[i];
+    for (int k = 0; k < nd; ++k) v[w++] = (S[L.dof_pos + k] - c.default_dof_pos[k]) * c.obs_scale_dof_pos;
+    for (int k = 0; k < nd; ++k) v[w++] = S[L.dof_vel + k] * c.obs_scale_dof_vel;
+    for (int k = 0; k < na; ++k) v[w++] = S[L.actions + k];
+    if (c.measure_heights)
+      for (int j = 0; j < c.num_height_points; ++j) v[w++] = clipf((S[L.root + 2] - 0.5f) - heights[j], -1.0f, 1.0f) * c.obs_scale_height;
+    for (int i = 0; i < no; ++i) {
+      float t = v[i];
+      if (c.add_noise) t += (2.0f * rnd(x, env, L.r_obs + i) - 1.0f) * c.obs_noise_vec[i];
+      obs[i] = clipf(t, -c.clip_obs, c.clip_obs);
+    }
+    return;
+  }
   float o[PF_MAX_OBS];
   int w = 0;
   for (int i = 0; i < 3; ++i) o[w++] = S[L.base_ang_vel + i] * c.obs_scale_ang_vel;
@@ -537,6 +603,8 @@ void post_physics(const Ctx& x, int env, float* S) {
   const PfModel& m = *x.m; const PfConfig& c = *x.c; const PfLayout& L = *x.L; const PfBuffers& B = *x.b;
   const int nd = m.nd, nf = m.nfeet, H = c.num_height_points;
   int64_t ep = B.d_episode_length[env] + 1;                  // :204
+  const bool LR = c.env_kind == PF_KIND_LEGGED_ROBOT;
+  if (LR && c.resample_interval > 0 && (ep % c.resample_interval) == 0) resample_commands(x, env, S, L.r_cmd);   // legged_robot.py:323-324
   // :208-211
   const float* q = S + L.root + 3;
   float grav[3] = {0.0f, 0.0f, -1.0f};
@@ -555,8 +623,8 @@ void post_physics(const Ctx& x, int env, float* S) {
     }
     if (B.d_measured_heights) std::memcpy(B.d_measured_heights + (size_t)env * H, heights, sizeof(float) * H);
   }
-  // :1114-1129 _compute_feet_states
-  for (int f = 0; f < nf; ++f) {
+  // :1114-1129 _compute_feet_states (PointFoot only)
+  for (int f = 0; f < (LR ? 0 : nf); ++f) {
     bool first = S[L.first_contact + f] != 0.0f, filt = S[L.contact_filt + f] != 0.0f;
     S[L.last_feet_air_time + f] = first ? S[L.feet_air_time + f] : S[L.last_feet_air_time + f];
     if (filt) S[L.feet_air_time + f] = 0.0f * S[L.feet_air_time + f];
@@ -584,7 +652,13 @@ void post_physics(const Ctx& x, int env, float* S) {
     float heading = std::atan2(fw[1], fw[0]);
     S[L.commands + 2] = clipf(0.5f * wrap_to_pi(S[L.commands + 3] - heading), -1.0f, 1.0f);
   }
-  if (c.push_robots && (x.step_counter % c.push_interval == 0)) {   // :590-611
+  // the base-frame velocities used by rewards/obs were taken before the push (legged_robot.py:112-117 vs :334-335)
+  float blv_[3] = {S[L.base_lin_vel], S[L.base_lin_vel + 1], S[L.base_lin_vel + 2]};
+  (void)blv_;
+  if (LR && c.push_robots && (x.step_counter % c.push_interval == 0)) {   // legged_robot.py:414-419
+    for (int i = 0; i < 2; ++i) S[L.root + 7 + i] = (c.max_push_vel - (-c.max_push_vel)) * rnd(x, env, L.r_push + i) + (-c.max_push_vel);
+  }
+  if (!LR && c.push_robots && (x.step_counter % c.push_interval == 0)) {   // :590-611
     float f[3];
     for (int i = 0; i < 3; ++i) f[i] = (c.max_push_force - (-c.max_push_force)) * rnd(x, env, L.r_push + i) + (-c.max_push_force);
     quat_rotate_dir(q, f, +1.0f, S + L.ext_force);
@@ -636,7 +710,20 @@ void post_physics(const Ctx& x, int env, float* S) {
         v = std::exp(-(ex * ex + ey * ey) / c.tracking_sigma);
       } break;
       case PF_REW_TRACKING_ANG_VEL: { float e = S[L.commands + 2] - S[L.base_ang_vel + 2]; v = std::exp(-(e * e) / c.tracking_sigma); } break;
-      case PF_REW_FEET_AIR_TIME: {
+      case PF_REW_FEET_AIR_TIME: if (LR) {      // legged_robot.py:882-893
+        float acc = 0.0f;
+        for (int f = 0; f < nf; ++f) {
+          bool contact = S[L.contact_forces + 3 * m.feet_body[f] + 2] > 1.0f;
+          bool filt = contact || (S[L.last_contacts + f] != 0.0f);
+          S[L.last_contacts + f] = contact ? 1.0f : 0.0f;
+          float first = (S[L.feet_air_time + f] > 0.0f && filt) ? 1.0f : 0.0f;
+          S[L.feet_air_time + f] += c.dt;
+          acc += (S[L.feet_air_time + f] - 0.5f) * first;
+          if (filt) S[L.feet_air_time + f] = S[L.feet_air_time + f] * 0.0f;
+        }
+        float cn = std::sqrt(S[L.commands] * S[L.commands] + S[L.commands + 1] * S[L.commands + 1]);
+        v = acc * (cn > 0.1f ? 1.0f : 0.0f);
+      } else {
         float lo = 0.0f, hi = 0.0f;
         for (int f = 0; f < nf; ++f) {
           float fc = S[L.first_contact + f];
@@ -656,7 +743,12 @@ void post_physics(const Ctx& x, int env, float* S) {
       case PF_REW_STUMBLE:
         for (int f = 0; f < nf; ++f) { const float* F = S + L.contact_forces + 3 * m.feet_body[f]; if (std::sqrt(F[0] * F[0] + F[1] * F[1]) > 5.0f * std::fabs(F[2])) v = 1.0f; }
         break;
-      case PF_REW_STAND_STILL:
+      case PF_REW_STAND_STILL: if (LR) {      // legged_robot.py:900-902
+        float sm = 0.0f;
+        for (int k = 0; k < nd; ++k) sm += std::fabs(S[L.dof_pos + k] - c.default_dof_pos[k]);
+        float cn = std::sqrt(S[L.commands] * S[L.commands] + S[L.commands + 1] * S[L.commands + 1]);
+        v = sm * (cn < 0.1f ? 1.0f : 0.0f);
+      } else
         v = (std::fabs(S[L.base_lin_vel]) * (S[L.commands] < 0.1f ? 1.0f : 0.0f) + std::fabs(S[L.base_lin_vel + 1]) * (S[L.commands + 1] < 0.1f ? 1.0f : 0.0f)) +
             std::fabs(S[L.base_ang_vel + 2]) * (S[L.commands + 2] < 0.1f ? 1.0f : 0.0f);
         break;
@@ -708,6 +800,7 @@ void post_physics(const Ctx& x, int env, float* S) {
     if (c.custom_origins)
       for (int i = 0; i < 2; ++i) S[L.root + i] += (1.0f - (-1.0f)) * rnd(x, env, L.r_xy + i) + (-1.0f);
     for (int i = 0; i < 6; ++i) S[L.root + 7 + i] = (0.5f - (-0.5f)) * rnd(x, env, L.r_vel + i) + (-0.5f);
+    if (LR) { resample_commands(x, env, S, L.r_cmd_reset); for (int e = 0; e < 32 * nd; ++e) S[L.lstm_state + e] = 0.0f; }   // legged_robot.py:168, anymal.py:56-60
     for (int f = 0; f < nf; ++f) {                         // :290-299
       S[L.feet_air_time + f] = 0.0f; S[L.last_feet_air_time + f] = 0.0f;
       S[L.cur_max_feet_height + f] = 0.0f; S[L.last_max_feet_height + f] = 0.0f;
@@ -764,7 +857,8 @@ int pfo_step(const PfModel* model, const PfConfig* cfg, const PfLayout* layout, 
       for (int i = 0; i < model->nfeet * 3; ++i) S[L.feet_pos + i] = inject->d_feet_pos[(size_t)env * model->nfeet * 3 + i];
     } else {
       for (int sub = 0; sub < c.decimation; ++sub) {   // :180-185
-        compute_torques(x, S, S + L.dof_pos, S + L.dof_vel);
+        if (c.env_kind == PF_KIND_LEGGED_ROBOT && c.use_actuator_net && bufs->d_actuator_params) actuator_torques(x, S);
+        else compute_torques(x, S, S + L.dof_pos, S + L.dof_vel);
         bool ext = sub == 0 && S[L.ext_force + 3] != 0.0f;
         if (physics_bits == 64) physics_substep<double>(x, S, ext); else physics_substep<float>(x, S, ext);
         if (ext) S[L.ext_force + 3] = 0.0f;

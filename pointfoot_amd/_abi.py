@@ -11,12 +11,14 @@ PF_MAX_DOF = 12
 PF_MAX_FEET = 4
 PF_MAX_SPHERES = 32
 PF_MAX_REWARDS = 32
-PF_MAX_OBS = 64
+PF_MAX_OBS = 256
 PF_MAX_HPTS = 192
 PF_MAX_TERM = 8
 PF_MAX_PEN = 20
 PPO_MAX_LAYERS = 4
 PF_STATS_FLOATS = PF_MAX_REWARDS + 4
+PF_ACT_PARAMS = 972
+PF_KIND_POINTFOOT, PF_KIND_LEGGED_ROBOT = 0, 1
 
 # order = enum PfReward
 REWARD_IDS = {name: i for i, name in enumerate([
@@ -74,6 +76,8 @@ class PfConfig(C.Structure):
         ("terrain_friction", f32), ("terrain_restitution", f32), ("contact_offset", f32),
         ("bounce_threshold", f32), ("max_depenetration_vel", f32), ("solver_iterations", i32),
         ("seed_lo", u32), ("seed_hi", u32),
+        ("env_kind", i32), ("resample_interval", i32), ("use_actuator_net", i32),
+        ("cmd_lo", f32 * 4), ("cmd_hi", f32 * 4), ("max_push_vel", f32),
     ]
 
 
@@ -83,8 +87,8 @@ class PfLayout(C.Structure):
         "commands", "torques", "base_lin_vel", "base_ang_vel", "projected_gravity",
         "feet_air_time", "last_feet_air_time", "cur_max_feet_height", "last_max_feet_height", "feet_height",
         "contact_filt", "first_contact", "last_contacts", "contact_forces", "feet_pos", "ext_force", "env_origin",
-        "friction", "added_mass", "added_com", "episode_sums",
-        "rand_floats", "r_obs", "r_priv", "r_dof", "r_xy", "r_vel", "r_level", "r_push")]
+        "friction", "added_mass", "added_com", "lstm_state", "episode_sums",
+        "rand_floats", "r_obs", "r_priv", "r_dof", "r_xy", "r_vel", "r_level", "r_push", "r_cmd", "r_cmd_reset")]
 
 
 vp = C.c_void_p
@@ -93,7 +97,8 @@ vp = C.c_void_p
 class PfBuffers(C.Structure):
     _fields_ = [(n, vp) for n in (
         "d_state", "d_episode_length", "d_terrain_level", "d_terrain_type", "d_reset", "d_time_out", "d_terminate",
-        "d_obs", "d_priv", "d_rew", "d_measured_heights", "d_height_samples", "d_terrain_origins", "d_reset_stats")]
+        "d_obs", "d_priv", "d_rew", "d_measured_heights", "d_height_samples", "d_terrain_origins", "d_actuator_params",
+        "d_reset_stats")]
 
 
 class PfInject(C.Structure):

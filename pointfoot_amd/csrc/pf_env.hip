@@ -27,9 +27,9 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // touches its own record, so no inter-workgroup ordering is needed.
 // model / cfg are separate __restrict__ const kernel arguments so the compiler can prove they are invariant and
 // read them with scalar loads (s_load) into SGPRs instead of holding hundreds of config values in VGPRs.
-template <int NB, int ND, int NF, int WAVES>
+template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT>
 __global__ __launch_bounds__(64, WAVES) void pf_step_kernel(const PfModel* __restrict__ model, const PfConfig* __restrict__ cfg, PfStepArgs g) {
-  using K = PfKernel<NB, ND, NF>;
+  using K = PfKernel<NB, ND, NF, KIND>;
   __shared__ typename K::Shared sh;
   g.model = model; g.cfg = cfg;
   K::run(sh, g, (int)blockIdx.x);
@@ -44,6 +44,7 @@ struct PfEnv {
   PfConfig* d_cfg = nullptr;
   int device = 0;
   bool bound = false;
+  int instance = 0;
   unsigned* d_stamps = nullptr;   // diagnostic build (-DPF_STAMPS) only
 };
 
@@ -60,20 +61,28 @@ void pf_abi_sizes(int64_t* sizes, int32_t n) {
 int pf_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out) {
   if (!model || !cfg || !out) { pf_set_error("pf_layout: null argument"); return 1; }
   pf_compute_layout(model, cfg, out);
-  if (out->rec_floats > PF_REC_MAX) { pf_set_error("pf_layout: state record exceeds PF_REC_MAX"); return 1; }
   return 0;
 }
 
+// kernel instances built: PointFoot PF_P441A (9 bodies / 6 dofs / 2 feet) and LeggedRobot ANYmal-C (17 / 12 / 4)
+static int pf_instance(const PfModel* m, const PfConfig* c) {
+  if (c->env_kind == PF_KIND_POINTFOOT && m->nb == 9 && m->nd == 6 && m->nfeet == 2) return 0;
+  if (c->env_kind == PF_KIND_LEGGED_ROBOT && m->nb == 17 && m->nd == 12 && m->nfeet == 4) return 1;
+  return -1;
+}
 static int pf_validate(const PfModel* m, const PfConfig* c) {
-  if (!(m->nb == 9 && m->nd == 6 && m->nfeet == 2)) {
-    pf_set_error("pf_create: no kernel instance for this model (built: 9 bodies / 6 dofs / 2 feet)");
+  int inst = pf_instance(m, c);
+  if (inst < 0) {
+    pf_set_error("pf_create: no kernel instance for this model / env kind (built: PointFoot 9 bodies/6 dofs/2 feet, LeggedRobot 17/12/4)");
     return 1;
   }
+  int want_obs = inst == 0 ? 9 + 3 * m->nd : 12 + 3 * m->nd + c->num_height_points;
   if (m->nsph > PF_KSPH || c->num_obs > PF_MAX_OBS || c->num_height_points > PF_MAX_HPTS ||
-      c->num_rewards >= PF_MAX_REWARDS || c->num_actions != m->nd || c->num_obs != 9 + 3 * m->nd) {
+      c->num_rewards >= PF_MAX_REWARDS || c->num_actions != m->nd || c->num_obs != want_obs) {
     pf_set_error("pf_create: configuration outside the compiled limits");
     return 1;
   }
+  if (inst == 1 && c->num_priv_obs != 0) { pf_set_error("pf_create: LeggedRobot has no privileged observations"); return 1; }
   for (int i = 1; i < m->nb; ++i)
     if (m->parent[i] < 0 || m->parent[i] >= i) { pf_set_error("pf_create: bodies must be in depth-first order"); return 1; }
   return 0;
@@ -85,8 +94,10 @@ PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device) {
   PfEnv* e = new PfEnv();
   e->model = *model; e->cfg = *cfg; e->device = device;
   pf_compute_layout(model, cfg, &e->layout);
-  if (e->layout.rec_floats > PF_REC_MAX) { pf_set_error("pf_create: state record exceeds PF_REC_MAX"); delete e; return nullptr; }
-  if (!PfKernel<9, 6, 2>::layout_matches(e->layout)) { pf_set_error("pf_create: record layout differs from the kernel's compile-time layout"); delete e; return nullptr; }
+  e->instance = pf_instance(model, cfg);
+  bool lay_ok = e->instance == 0 ? PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::layout_matches(e->layout)
+                                 : PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT>::layout_matches(e->layout);
+  if (!lay_ok) { pf_set_error("pf_create: record layout differs from the kernel's compile-time layout"); delete e; return nullptr; }
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&e->d_model, sizeof(PfModel)) != hipSuccess ||
       hipMalloc(&e->d_cfg, sizeof(PfConfig)) != hipSuccess ||
       hipMemcpy(e->d_model, model, sizeof(PfModel), hipMemcpyHostToDevice) != hipSuccess ||
@@ -114,6 +125,9 @@ int pf_bind_buffers(PfEnv* e, const PfBuffers* b) {
   if (e->cfg.num_priv_obs > 0 && !b->d_priv) { pf_set_error("pf_bind_buffers: d_priv required"); return 1; }
   if (e->cfg.terrain_type == PF_TERRAIN_HEIGHTFIELD && (!b->d_height_samples || e->cfg.hf_rows < 2 || e->cfg.hf_cols < 2)) {
     pf_set_error("pf_bind_buffers: height field required for this terrain type"); return 1;
+  }
+  if (e->cfg.env_kind == PF_KIND_LEGGED_ROBOT && e->cfg.use_actuator_net && !b->d_actuator_params) {
+    pf_set_error("pf_bind_buffers: actuator network parameters required (use_actuator_net)"); return 1;
   }
   if (e->cfg.curriculum && (!b->d_terrain_level || !b->d_terrain_type || !b->d_terrain_origins)) {
     pf_set_error("pf_bind_buffers: terrain curriculum buffers required"); return 1;
@@ -158,7 +172,8 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   // PF_STEP_WAVES selects the register budget variant (waves per SIMD the kernel is compiled for)
   static const int variant = [] { const char* v = getenv("PF_STEP_WAVES"); return v ? atoi(v) : 4; }();
   dim3 grid(e->cfg.num_envs), block(64);
-  if (variant == 4) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 4>), grid, block, 0, s, e->d_model, e->d_cfg, g);
+  if (e->instance == 1) hipLaunchKernelGGL((pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT>), grid, block, 0, s, e->d_model, e->d_cfg, g);
+  else if (variant == 4) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 4>), grid, block, 0, s, e->d_model, e->d_cfg, g);
   else if (variant == 3) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 3>), grid, block, 0, s, e->d_model, e->d_cfg, g);
   else hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 2>), grid, block, 0, s, e->d_model, e->d_cfg, g);
   PF_HIP_OK(hipGetLastError());

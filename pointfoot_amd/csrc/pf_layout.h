@@ -34,6 +34,7 @@ static inline int pf_compute_layout(const PfModel* m, const PfConfig* c, PfLayou
   L->friction = take(1);
   L->added_mass = take(1);
   L->added_com = take(3);
+  L->lstm_state = take(c->env_kind == PF_KIND_LEGGED_ROBOT ? 32 * nd : 0);
   L->episode_sums = take(c->num_rewards + 1);
   L->rec_floats = (o + 15) & ~15;   // 64-byte multiple
   int r = 0;
@@ -45,6 +46,8 @@ static inline int pf_compute_layout(const PfModel* m, const PfConfig* c, PfLayou
   L->r_vel = rtake(6);
   L->r_level = rtake(1);
   L->r_push = rtake(3);
+  L->r_cmd = rtake(3);
+  L->r_cmd_reset = rtake(3);
   L->rand_floats = (r + 3) & ~3;
   return 0;
 }

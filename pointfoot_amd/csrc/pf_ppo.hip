@@ -252,15 +252,15 @@ __global__ void k_loss(int B, int A, float clip, float vcoef, float ecoef, int c
                        const float* __restrict__ old_val, float* __restrict__ dmean, float* __restrict__ dvalue,
                        float* __restrict__ partial) {
   __shared__ float sm[8];
-  float dstd[8], kl = 0.0f, vl = 0.0f, sl = 0.0f, en = 0.0f;
+  float dstd[16], kl = 0.0f, vl = 0.0f, sl = 0.0f, en = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) dstd[k] = 0.0f;
+  for (int k = 0; k < 16; ++k) dstd[k] = 0.0f;
   const float invB = 1.0f / (float)B;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
     float lp = 0.0f, kls = 0.0f, ens = 0.0f;
-    float dmu[8], dsg[8];
+    float dmu[16], dsg[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (k < A) {
+    for (int k = 0; k < 16; ++k) if (k < A) {
       float mu = mean[(size_t)i * A + k], sg = stdp[k], a = act[(size_t)i * A + k];
       float d = a - mu;
       lp += -0.5f * (d * d) / (sg * sg) - logf(sg) - 0.91893853320467274178f;
@@ -286,14 +286,15 @@ __global__ void k_loss(int B, int A, float clip, float vcoef, float ecoef, int c
     } else { gv = 2.0f * (v - r); vl += (r - v) * (r - v); }
     dvalue[i] = vcoef * gv * invB;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (k < A) {
+    for (int k = 0; k < 16; ++k) if (k < A) {
       dmean[(size_t)i * A + k] = g_lp * dmu[k];
       dstd[k] += g_lp * dsg[k];
     }
     kl += kls; en += ens;
   }
   float* out = partial + (size_t)blockIdx.x * (A + 4);
-  for (int k = 0; k < A; ++k) { float s = block_sum(dstd[k], sm); if (threadIdx.x == 0) out[k] = s; }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) if (k < A) { float s = block_sum(dstd[k], sm); if (threadIdx.x == 0) out[k] = s; }
   float s;
   s = block_sum(kl, sm); if (threadIdx.x == 0) out[A] = s;
   s = block_sum(vl, sm); if (threadIdx.x == 0) out[A + 1] = s;
@@ -303,16 +304,16 @@ __global__ void k_loss(int B, int A, float clip, float vcoef, float ecoef, int c
 // finish the loss reductions: dL/dstd (incl. the entropy bonus), KL sum + count for the adaptive LR
 __global__ void k_loss_finish(int nb, int A, int B, float ecoef, const float* __restrict__ partial, const float* __restrict__ stdp,
                               float* __restrict__ dstd, float* __restrict__ grads_tail, float* __restrict__ scalars) {
-  // 16 columns x 16 row-lanes: lane (c, r) sums rows r, r+16, ... of column c; fixed-order combine in LDS
-  __shared__ float sm[16][17];
-  int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  // 32 columns x 8 row-lanes: lane (c, r) sums rows r, r+8, ... of column c; fixed-order combine in LDS
+  __shared__ float sm[8][33];
+  int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   float s = 0.0f;
-  if (c < A + 4) for (int b = r; b < nb; b += 16) s += partial[(size_t)b * (A + 4) + c];
+  if (c < A + 4) for (int b = r; b < nb; b += 8) s += partial[(size_t)b * (A + 4) + c];
   sm[r][c] = s;
   __syncthreads();
   if (r == 0 && c < A + 4) {
     float t = 0.0f;
-    for (int i = 0; i < 16; ++i) t += sm[i][c];
+    for (int i = 0; i < 8; ++i) t += sm[i][c];
     if (c < A) dstd[c] = t - ecoef / stdp[c];
     else if (c == A) { grads_tail[0] = t; grads_tail[1] = (float)B; }
     else if (c == A + 1) scalars[SC_VLOSS] += t / (float)B;
@@ -398,7 +399,7 @@ static int ppo_check_cfg(const PpoConfig* c) {
   if (c->n_actor_layers < 2 || c->n_actor_layers > PPO_MAX_LAYERS || c->n_critic_layers < 2 || c->n_critic_layers > PPO_MAX_LAYERS) {
     pf_set_error("ppo: 1..3 hidden layers supported"); return 1;
   }
-  if (c->num_actions < 1 || c->num_actions > 8) { pf_set_error("ppo: num_actions must be in 1..8"); return 1; }
+  if (c->num_actions < 1 || c->num_actions > 16) { pf_set_error("ppo: num_actions must be in 1..16"); return 1; }
   if (c->actor_dims[0] != c->num_obs || c->critic_dims[0] != c->num_critic_obs || c->actor_dims[c->n_actor_layers] != c->num_actions ||
       c->critic_dims[c->n_critic_layers] != 1) { pf_set_error("ppo: layer dims inconsistent with obs/action sizes"); return 1; }
   if ((c->num_envs * c->num_steps) % c->num_mini_batches != 0) { pf_set_error("ppo: num_envs*num_steps must divide by num_mini_batches"); return 1; }
@@ -431,8 +432,8 @@ static void ppo_plan(PpoAlg* a) {
   a->w_dmean = take(R * c.num_actions); a->w_dvalue = take(R);
   a->w_g[0] = take(R * mw); a->w_g[1] = take(R * mw);
   size_t thin_blocks = (R + 31) / 32;
-  a->w_slabs = take(std::max<size_t>((size_t)a->splits * (maxw + mw), thin_blocks * (8 * 1024 + 8)));
-  a->w_partial = take((size_t)RED_BLOCKS * 16);
+  a->w_slabs = take(std::max<size_t>((size_t)a->splits * (maxw + mw), thin_blocks * (16 * 1024 + 16)));
+  a->w_partial = take((size_t)RED_BLOCKS * 24);
   a->w_lastval = take(c.num_envs);
   a->w_total = w;
 }
@@ -446,7 +447,7 @@ static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const si
     float* out = ws + w_h[i];
     if (i == n.nl - 1) {
       int threads = 256, rows_per_block = threads / 8;
-      hipLaunchKernelGGL((k_thin_fwd<8>), dim3((M + rows_per_block - 1) / rows_per_block), dim3(threads), sizeof(float) * L.out * L.in, s,
+      hipLaunchKernelGGL((k_thin_fwd<16>), dim3((M + rows_per_block - 1) / rows_per_block), dim3(threads), sizeof(float) * L.out * L.in, s,
                          M, L.in, L.out, in, P + L.w, P + L.b, out);
     } else {
       GemmArgs g{};
@@ -469,7 +470,7 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
     const Layer& L = n.l[last];
     int rows_per_block = 32, nblk = (M + rows_per_block - 1) / rows_per_block;
     int threads = (L.in + 63) / 64 * 64;
-    hipLaunchKernelGGL((k_thin_bwd<8>), dim3(nblk), dim3(threads), 0, s, M, L.in, L.out, rows_per_block, dHead, ws + w_h[last - 1], P + L.w,
+    hipLaunchKernelGGL((k_thin_bwd<16>), dim3(nblk), dim3(threads), 0, s, M, L.in, L.out, rows_per_block, dHead, ws + w_h[last - 1], P + L.w,
                        gcur, slabs);
     int nw = L.out * L.in + L.out;       // W then b, contiguous in the flat gradient buffer
     hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, s, nw, nblk, slabs, G + L.w);

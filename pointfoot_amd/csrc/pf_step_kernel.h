@@ -126,8 +126,10 @@ struct PfStepArgs {
   unsigned* stamps;       // diagnostic build only, else NULL
 };
 
-template <int NB, int ND, int NF>
+template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT>
 struct PfKernel {
+  static constexpr bool LR = KIND == PF_KIND_LEGGED_ROBOT;      // LeggedRobot / Anymal semantics (legged_robot.py)
+  static constexpr int REC_MAX = LR ? 704 : PF_REC_MAX;
   static constexpr int NV = 6 + ND;
   static constexpr int NVP = NV | 1;          // odd row stride: per-lane rows hit distinct LDS banks
   static constexpr int MAXC = PF_MAXC;
@@ -148,7 +150,7 @@ struct PfKernel {
                          contact_filt = feet_height + NF, first_contact = contact_filt + NF, last_contacts = first_contact + NF,
                          contact_forces = last_contacts + NF, feet_pos = contact_forces + 3 * NB, ext_force = feet_pos + 3 * NF,
                          env_origin = ext_force + 4, friction = env_origin + 3, added_mass = friction + 1, added_com = added_mass + 1,
-                         episode_sums = added_com + 3;
+                         lstm_state = added_com + 3, episode_sums = lstm_state + (LR ? 32 * ND : 0);
   };
   static bool layout_matches(const PfLayout& L) {
     return L.root == LC::root && L.dof_pos == LC::dof_pos && L.dof_vel == LC::dof_vel && L.actions == LC::actions &&
@@ -159,7 +161,8 @@ struct PfKernel {
            L.last_max_feet_height == LC::last_max_feet_height && L.feet_height == LC::feet_height && L.contact_filt == LC::contact_filt &&
            L.first_contact == LC::first_contact && L.last_contacts == LC::last_contacts && L.contact_forces == LC::contact_forces &&
            L.feet_pos == LC::feet_pos && L.ext_force == LC::ext_force && L.env_origin == LC::env_origin && L.friction == LC::friction &&
-           L.added_mass == LC::added_mass && L.added_com == LC::added_com && L.episode_sums == LC::episode_sums;
+           L.added_mass == LC::added_mass && L.added_com == LC::added_com && L.lstm_state == LC::lstm_state &&
+           L.episode_sums == LC::episode_sums && L.rec_floats <= REC_MAX;
   }
 
   // The robot model, re-packed to this instance's sizes and staged in LDS once per launch: the per-body / per-sphere
@@ -183,7 +186,9 @@ struct PfKernel {
     unsigned long long stamp_last;
     unsigned stamp_acc[PF_NSTAMP];
 #endif
-    float rec[PF_REC_MAX];
+    float rec[REC_MAX];
+    float act[LR ? PF_ACT_PARAMS : 1];        // actuator-net parameters (LeggedRobot)
+    float gates[LR ? ND * 32 : 1];            // LSTM gate pre-activations
     float Rw[NB][9], r[NB][3], ax[NB][3];
     float Sj[NB][6], V[NB][6], A[NB][6];      // {ang, lin@O}
     float I[NB][10], Ic[NB][10];
@@ -238,6 +243,49 @@ struct PfKernel {
   PF_DEV float rnd(const PfConfig& c, const PfLayout& L, const PfInject& inj, int env, long long step, int slot) {
     if (inj.d_rand) return inj.d_rand[(size_t)env * L.rand_floats + slot];
     return pf_philox_slot(c.seed_lo, c.seed_hi, (uint32_t)(c.env_index_base + env), (uint32_t)step, 0u, (uint32_t)slot);
+  }
+
+  // ------------------------------------------------------------------ actuator network (anymal.py:71-78)
+  // per joint: x = [a*scale + q0 - q, qd] * in_scale -> LSTM(2->8) x 2 layers (state h,c persists, zeroed on reset) ->
+  // Linear(8->1) * out_scale.  No torque clip on this branch.  Lanes: (joint, gate row) pairs, then (joint, unit) pairs.
+  PF_DEV float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+  PF_DEV void actuator_torques(Shared& sh, const PfConfig& c) {
+    float* S = sh.rec; const float* P = sh.act;
+    for (int layer = 0; layer < 2; ++layer) {
+      PF_LANES(e, ND * 32) {
+        int j = e >> 5, g = e & 31;
+        float* st = S + LC::lstm_state + j * 32;          // [layer][h(8) c(8)]
+        float acc;
+        if (layer == 0) {
+          float x0 = ((S[LC::actions + j] * c.action_scale + c.default_dof_pos[j]) - S[LC::dof_pos + j]) * P[PF_ACT_IN_SCALE];
+          float x1 = S[LC::dof_vel + j] * P[PF_ACT_IN_SCALE + 1];
+          acc = P[PF_ACT_B_IH0 + g] + P[PF_ACT_B_HH0 + g] + P[PF_ACT_W_IH0 + 2 * g] * x0 + P[PF_ACT_W_IH0 + 2 * g + 1] * x1;
+          for (int t = 0; t < 8; ++t) acc += P[PF_ACT_W_HH0 + 8 * g + t] * st[t];
+        } else {
+          acc = P[PF_ACT_B_IH1 + g] + P[PF_ACT_B_HH1 + g];
+          for (int t = 0; t < 8; ++t) acc += P[PF_ACT_W_IH1 + 8 * g + t] * st[t] + P[PF_ACT_W_HH1 + 8 * g + t] * st[16 + t];
+        }
+        sh.gates[e] = acc;
+      }
+      PF_SYNC();
+      PF_LANES(e, ND * 8) {
+        int j = e >> 3, u = e & 7;
+        const float* G = sh.gates + j * 32;
+        float* st = S + LC::lstm_state + j * 32 + layer * 16;
+        float ig = sigm(G[u]), fg = sigm(G[8 + u]), gg = tanhf(G[16 + u]), og = sigm(G[24 + u]);
+        float cn = fg * st[8 + u] + ig * gg;
+        st[8 + u] = cn;
+        st[u] = og * tanhf(cn);
+      }
+      PF_SYNC();
+    }
+    PF_LANES(j, ND) {
+      const float* h2 = S + LC::lstm_state + j * 32 + 16;
+      float y = P[PF_ACT_B_LIN];
+      for (int t = 0; t < 8; ++t) y += P[PF_ACT_W_LIN + t] * h2[t];
+      S[LC::torques + j] = y * P[PF_ACT_OUT_SCALE];
+    }
+    PF_SYNC();
   }
 
   // ------------------------------------------------------------------ PD torques (:523-547)
@@ -723,6 +771,24 @@ struct PfKernel {
     const float* S = sh.rec;
     const float* hts = heights_of(sh);
     const int no = c.num_obs, np_ = c.num_priv_obs, na = c.num_actions;
+    if constexpr (LR) {
+      // obs = [lin_vel*s (3), ang_vel*s (3), gravity (3), cmd[:3]*scale (3), q-q0 (ND), qd*s (ND), actions (ND), heights (H)]
+      const int nprop = 12 + 3 * ND;
+      PF_LANES(i, no) {
+        float v;
+        if (i < 3) v = S[LC::base_lin_vel + i] * c.obs_scale_lin_vel;
+        else if (i < 6) v = S[LC::base_ang_vel + i - 3] * c.obs_scale_ang_vel;
+        else if (i < 9) v = S[LC::projected_gravity + i - 6];
+        else if (i < 12) v = S[LC::commands + i - 9] * c.commands_scale[i - 9];
+        else if (i < 12 + ND) v = (S[LC::dof_pos + i - 12] - c.default_dof_pos[i - 12]) * c.obs_scale_dof_pos;
+        else if (i < 12 + 2 * ND) v = S[LC::dof_vel + i - 12 - ND] * c.obs_scale_dof_vel;
+        else if (i < nprop) v = S[LC::actions + i - 12 - 2 * ND];
+        else v = pf_clip((S[LC::root + 2] - 0.5f) - hts[i - nprop], -1.0f, 1.0f) * c.obs_scale_height;
+        if (c.add_noise) v += (2.0f * rnd(c, L, inj, env, step, L.r_obs + i) - 1.0f) * c.obs_noise_vec[i];
+        B.d_obs[(size_t)env * no + i] = pf_clip(v, -c.clip_obs, c.clip_obs);
+      }
+      return;
+    }
     PF_LANES(i, no) {
       float v;
       if (i < 3) v = S[LC::base_ang_vel + i] * c.obs_scale_ang_vel;
@@ -743,6 +809,22 @@ struct PfKernel {
         B.d_priv[(size_t)env * np_ + no + j] = pf_clip(h, -c.clip_obs, c.clip_obs);
       }
     }
+  }
+
+  // ------------------------------------------------------------------ _resample_commands (legged_robot.py:337-351)
+  PF_DEV void resample_commands(Shared& sh, const PfConfig& c, const PfLayout& L, const PfInject& inj, int env, long long step, int slot) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+    float* S = sh.rec;
+    float cx = (c.cmd_hi[0] - c.cmd_lo[0]) * rnd(c, L, inj, env, step, slot) + c.cmd_lo[0];
+    float cy = (c.cmd_hi[1] - c.cmd_lo[1]) * rnd(c, L, inj, env, step, slot + 1) + c.cmd_lo[1];
+    int k = c.heading_command ? 3 : 2;
+    float cz = (c.cmd_hi[k] - c.cmd_lo[k]) * rnd(c, L, inj, env, step, slot + 2) + c.cmd_lo[k];
+    float keep = sqrtf(cx * cx + cy * cy) > 0.2f ? 1.0f : 0.0f;      // set small commands to zero
+    PF_SYNC();
+    PF_ONE { S[LC::commands] = cx * keep; S[LC::commands + 1] = cy * keep; S[LC::commands + k] = cz; }
+    PF_SYNC();
   }
 
   // ------------------------------------------------------------------ reset_idx for this env (:249-299)
@@ -780,10 +862,12 @@ struct PfKernel {
       if (i >= 7) v = (0.5f - (-0.5f)) * rnd(c, L, inj, env, step, L.r_vel + i - 7) + (-0.5f);
       S[LC::root + i] = v;
     }
+    if constexpr (LR) resample_commands(sh, c, L, inj, env, step, L.r_cmd_reset);     // legged_robot.py:168
     PF_LANES(f, NF) {       // :290-299
       S[LC::feet_air_time + f] = 0.0f; S[LC::last_feet_air_time + f] = 0.0f;
       S[LC::cur_max_feet_height + f] = 0.0f; S[LC::last_max_feet_height + f] = 0.0f;
     }
+    if constexpr (LR) { PF_LANES(e, 32 * ND) S[LC::lstm_state + e] = 0.0f; }     // anymal.py:56-60
     int nsum = c.num_rewards + (c.termination_scale != 0.0f ? 1 : 0);
     PF_LANES(ri, nsum) {    // :276-280
       if (B.d_reset_stats) PF_ATOMIC_ADD(B.d_reset_stats + ri, S[LC::episode_sums + ri]);
@@ -816,6 +900,7 @@ struct PfKernel {
     PF_LANES(t, PF_MAX_TERM) ms.term_body[t] = gm.term_body[t];
     PF_LANES(t, PF_MAX_PEN) ms.pen_body[t] = gm.pen_body[t];
     PF_ONE { ms.nsph = gm.nsph; ms.n_term = gm.n_term; ms.n_pen = gm.n_pen; }
+    if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { PF_LANES(i, PF_ACT_PARAMS) sh.act[i] = B.d_actuator_params[i]; } }
     const ModelS& m = ms;
     float* S = sh.rec;
     bool need_chains = true;
@@ -870,7 +955,9 @@ struct PfKernel {
     } else {
       for (int sub = 0; sub < c.decimation; ++sub) {     // :180-185
         PF_STAMP(sh, 0);
-        torques(sh, c, L, S + LC::dof_pos, 1, LC::dof_vel - LC::dof_pos);
+        bool pd = true;
+        if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { actuator_torques(sh, c); pd = false; } }
+        if (pd) torques(sh, c, L, S + LC::dof_pos, 1, LC::dof_vel - LC::dof_pos);
         PF_STAMP(sh, 12);
         bool ext = sub == 0 && S[LC::ext_force + 3] != 0.0f;
         substep(sh, m, c, L, B, ext);
@@ -900,6 +987,9 @@ struct PfKernel {
     float* hts = heights_of(sh);
     const int H = c.num_height_points;
     long long ep = B.d_episode_length[env] + 1;      // :204
+    if constexpr (LR) {   // legged_robot.py:323-324: periodic command resampling comes first in the callback
+      if (c.resample_interval > 0 && (ep % c.resample_interval) == 0) resample_commands(sh, c, L, inj, env, step, L.r_cmd);
+    }
     float q[4] = {S[LC::root + 3], S[LC::root + 4], S[LC::root + 5], S[LC::root + 6]};
     // :208-211 (uniform; lane 0 stores)
     float blv[3], bav[3], pg[3];
@@ -928,8 +1018,8 @@ struct PfKernel {
       }
       hsum = PF_WAVE_SUM(hsum);
     }
-    // :1114-1129 feet state machine
-    PF_LANES(f, NF) {
+    // :1114-1129 feet state machine (PointFoot only; LeggedRobot keeps it inside _reward_feet_air_time)
+    if constexpr (!LR) PF_LANES(f, NF) {
       bool first = S[LC::first_contact + f] != 0.0f, filt = S[LC::contact_filt + f] != 0.0f;
       float air = S[LC::feet_air_time + f];
       S[LC::last_feet_air_time + f] = first ? air : S[LC::last_feet_air_time + f];
@@ -961,7 +1051,11 @@ struct PfKernel {
     }
     bool push = c.push_robots && (step % c.push_interval == 0);
     float ef[3] = {0.0f, 0.0f, 0.0f};
-    if (push) {     // :590-611
+    float pv[2] = {0.0f, 0.0f};
+    if (LR && push) {   // legged_robot.py:414-419: overwrite base lin-vel xy
+      for (int i = 0; i < 2; ++i) pv[i] = (c.max_push_vel - (-c.max_push_vel)) * rnd(c, L, inj, env, step, L.r_push + i) + (-c.max_push_vel);
+    }
+    if (!LR && push) {     // :590-611
       float fr[3];
       for (int i = 0; i < 3; ++i) fr[i] = (c.max_push_force - (-c.max_push_force)) * rnd(c, L, inj, env, step, L.r_push + i) + (-c.max_push_force);
       pf_quat_rotate_dir(q, fr, 1.0f, ef);
@@ -971,7 +1065,8 @@ struct PfKernel {
     PF_ONE {
       for (int t = 0; t < 3; ++t) { S[LC::base_lin_vel + t] = blv[t]; S[LC::base_ang_vel + t] = bav[t]; S[LC::projected_gravity + t] = pg[t]; }
       S[LC::commands + 2] = cmd2;
-      if (push) { S[LC::ext_force] = ef[0]; S[LC::ext_force + 1] = ef[1]; S[LC::ext_force + 2] = ef[2]; S[LC::ext_force + 3] = 1.0f; }
+      if (!LR && push) { S[LC::ext_force] = ef[0]; S[LC::ext_force + 1] = ef[1]; S[LC::ext_force + 2] = ef[2]; S[LC::ext_force + 3] = 1.0f; }
+      if (LR && push) { S[LC::root + 7] = pv[0]; S[LC::root + 8] = pv[1]; }
     }
     PF_SYNC();
     // :239-247 termination (uniform)
@@ -1006,7 +1101,20 @@ struct PfKernel {
         case PF_REW_TORQUE_LIMITS: for (int k = 0; k < ND; ++k) v += fmaxf(fabsf(S[LC::torques + k]) - c.torque_limits[k] * c.soft_torque_limit, 0.0f); break;
         case PF_REW_TRACKING_LIN_VEL: { float ex = S[LC::commands] - blv[0], ey = S[LC::commands + 1] - blv[1]; v = expf(-(ex * ex + ey * ey) / c.tracking_sigma); } break;
         case PF_REW_TRACKING_ANG_VEL: { float e = cmd2 - bav[2]; v = expf(-(e * e) / c.tracking_sigma); } break;
-        case PF_REW_FEET_AIR_TIME: {
+        case PF_REW_FEET_AIR_TIME: if constexpr (LR) {   // legged_robot.py:882-893 (state machine lives in the reward)
+          float acc = 0.0f;
+          for (int f = 0; f < NF; ++f) {
+            bool contact = S[LC::contact_forces + 3 * m.feet_body[f] + 2] > 1.0f;
+            bool filt = contact || (S[LC::last_contacts + f] != 0.0f);
+            float air = S[LC::feet_air_time + f];
+            float first = (air > 0.0f && filt) ? 1.0f : 0.0f;
+            air += c.dt;
+            acc += (air - 0.5f) * first;
+            if (PF_LANE_ID == 0) { S[LC::last_contacts + f] = contact ? 1.0f : 0.0f; S[LC::feet_air_time + f] = filt ? air * 0.0f : air; }
+          }
+          float cn = sqrtf(S[LC::commands] * S[LC::commands] + S[LC::commands + 1] * S[LC::commands + 1]);
+          v = acc * (cn > 0.1f ? 1.0f : 0.0f);
+        } else {
           float lo = 0.0f, hi = 0.0f;
           for (int f = 0; f < NF; ++f) { float fc = S[LC::first_contact + f], at = S[LC::feet_air_time + f]; lo += fminf(at - c.min_feet_air_time, 0.0f) * fc; hi += fminf(c.max_feet_air_time - at, 0.0f) * fc; }
           v = lo + hi;
@@ -1022,7 +1130,12 @@ struct PfKernel {
         case PF_REW_STUMBLE:
           for (int f = 0; f < NF; ++f) { const float* Fc = S + LC::contact_forces + 3 * m.feet_body[f]; if (sqrtf(Fc[0] * Fc[0] + Fc[1] * Fc[1]) > 5.0f * fabsf(Fc[2])) v = 1.0f; }
           break;
-        case PF_REW_STAND_STILL:
+        case PF_REW_STAND_STILL: if constexpr (LR) {      // legged_robot.py:900-902
+          float sm = 0.0f;
+          for (int k = 0; k < ND; ++k) sm += fabsf(S[LC::dof_pos + k] - c.default_dof_pos[k]);
+          float cn = sqrtf(S[LC::commands] * S[LC::commands] + S[LC::commands + 1] * S[LC::commands + 1]);
+          v = sm * (cn < 0.1f ? 1.0f : 0.0f);
+        } else
           v = (fabsf(blv[0]) * (S[LC::commands] < 0.1f ? 1.0f : 0.0f) + fabsf(blv[1]) * (S[LC::commands + 1] < 0.1f ? 1.0f : 0.0f)) + fabsf(bav[2]) * (cmd2 < 0.1f ? 1.0f : 0.0f);
           break;
         case PF_REW_FEET_CONTACT_FORCES:

@@ -46,7 +46,8 @@ def build_model(cfg):
             m.inertia[i][k] = t["inertia"][i][k]
     for k in range(nd):
         m.body_of_dof[k] = t["body_of_dof"][k]
-        m.q_lo[k], m.q_hi[k] = t["q_lo"][k], t["q_hi"][k]
+        lo, hi = t["q_lo"][k], t["q_hi"][k]
+        m.q_lo[k], m.q_hi[k] = (lo, hi) if hi > lo else (-1e9, 1e9)      # continuous joints (ANYmal): no position limit
         m.vel_limit[k], m.effort_limit[k] = t["vel_limit"][k], t["effort_limit"][k]
     # collision spheres: feet first so they survive the per-robot contact cap
     sph = sorted(t["spheres"], key=lambda s: (0 if s[0] in feet else 1))
@@ -65,13 +66,28 @@ def build_model(cfg):
         m.term_body[i] = b
     for i, b in enumerate(pen):
         m.pen_body[i] = b
-    info = dict(body_names=names, dof_names=t["dof_names"], feet_indices=feet, penalised_contact_indices=pen,
+    info = dict(body_names=names, dof_names=t["dof_names"], q_lo_raw=t["q_lo"], q_hi_raw=t["q_hi"], feet_indices=feet, penalised_contact_indices=pen,
                 termination_contact_indices=term, base_mass=t["mass"][0])
     return m, info
 
 
-def noise_scale_vec(cfg, num_dof):
-    """_get_noise_scale_vec (point_foot.py:652-695), including its misalignment with the obs layout."""
+def noise_scale_vec(cfg, num_dof, kind=_abi.PF_KIND_POINTFOOT):
+    """_get_noise_scale_vec: PointFoot (point_foot.py:652-695, including its misalignment with the obs layout) or
+    LeggedRobot (legged_robot.py:456-478, aligned, hard-coded for 12 DOF in the reference)."""
+    if kind == _abi.PF_KIND_LEGGED_ROBOT:
+        no = cfg.env.num_observations
+        vec = np.zeros(no, dtype=np.float32)
+        ns, lvl, sc = cfg.noise.noise_scales, cfg.noise.noise_level, cfg.normalization.obs_scales
+        vec[:3] = ns.lin_vel * lvl * sc.lin_vel
+        vec[3:6] = ns.ang_vel * lvl * sc.ang_vel
+        vec[6:9] = ns.gravity * lvl
+        vec[9:12] = 0.
+        vec[12:12 + num_dof] = ns.dof_pos * lvl * sc.dof_pos
+        vec[12 + num_dof:12 + 2 * num_dof] = ns.dof_vel * lvl * sc.dof_vel
+        vec[12 + 2 * num_dof:12 + 3 * num_dof] = 0.
+        if cfg.terrain.measure_heights:
+            vec[12 + 3 * num_dof:no] = ns.height_measurements * lvl * sc.height_measurements
+        return vec, None
     no = cfg.env.num_propriceptive_obs
     vec = np.zeros(no, dtype=np.float32)
     ns, lvl, sc = cfg.noise.noise_scales, cfg.noise.noise_level, cfg.normalization.obs_scales
@@ -110,14 +126,18 @@ def reward_table(cfg, dt):
 
 
 def build_config(cfg, model, info, sim_params, num_envs, *, env_index_base=0, num_envs_global=None,
-                 hf_shape=None, mean_base_mass=None, seed=1):
+                 hf_shape=None, mean_base_mass=None, seed=1, kind=_abi.PF_KIND_POINTFOOT):
     nd = model.nd
+    LR = kind == _abi.PF_KIND_LEGGED_ROBOT
     c = _abi.PfConfig()
     dt = cfg.control.decimation * sim_params.dt
+    c.env_kind = kind
     c.num_envs, c.env_index_base = num_envs, env_index_base
     c.num_envs_global = num_envs_global if num_envs_global is not None else num_envs
-    c.num_obs = cfg.env.num_propriceptive_obs
-    c.num_priv_obs = cfg.env.num_privileged_obs or 0
+    c.num_obs = cfg.env.num_observations if LR else cfg.env.num_propriceptive_obs
+    c.num_priv_obs = 0 if LR else (cfg.env.num_privileged_obs or 0)
+    if LR and cfg.env.num_privileged_obs is not None:
+        raise NotImplementedError("LeggedRobot with privileged observations is not built (no reference task uses it)")
     c.num_actions = cfg.env.num_actions
     if cfg.control.control_type not in _abi.PF_CTRL:
         raise NameError(f"Unknown controller type: {cfg.control.control_type}")
@@ -128,9 +148,12 @@ def build_config(cfg, model, info, sim_params, num_envs, *, env_index_base=0, nu
         raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
     rough = mesh in ('heightfield', 'trimesh')
     c.terrain_type = _abi.PF_TERRAIN_HEIGHTFIELD if rough else _abi.PF_TERRAIN_PLANE
-    c.measure_heights = int(bool(cfg.terrain.measure_heights_critic or cfg.terrain.measure_heights_actor))
-    if cfg.terrain.measure_heights_actor:
-        raise NotImplementedError("measure_heights_actor=True is not built (both PointFoot tasks use critic-only heights)")
+    if LR:
+        c.measure_heights = int(bool(cfg.terrain.measure_heights))
+    else:
+        c.measure_heights = int(bool(cfg.terrain.measure_heights_critic or cfg.terrain.measure_heights_actor))
+        if cfg.terrain.measure_heights_actor:
+            raise NotImplementedError("measure_heights_actor=True is not built (both PointFoot tasks use critic-only heights)")
     px, py = cfg.terrain.measured_points_x, cfg.terrain.measured_points_y
     H = len(px) * len(py) if c.measure_heights else 0
     if H > _abi.PF_MAX_HPTS:
@@ -154,7 +177,7 @@ def build_config(cfg, model, info, sim_params, num_envs, *, env_index_base=0, nu
     c.push_interval = int(np.ceil(cfg.domain_rand.push_interval_s / dt))
     c.add_noise = int(cfg.noise.add_noise)
     c.only_positive_rewards = int(cfg.rewards.only_positive_rewards)
-    c.include_feet_height = int(any("feet_height" in s for s in dir(cfg.rewards.scales) if not s.startswith("__")))
+    c.include_feet_height = 0 if LR else int(any("feet_height" in s for s in dir(cfg.rewards.scales) if not s.startswith("__")))
     names, scales = reward_table(cfg, dt)
     if len(names) > _abi.PF_MAX_REWARDS - 1:
         raise ValueError("too many reward terms")
@@ -181,7 +204,7 @@ def build_config(cfg, model, info, sim_params, num_envs, *, env_index_base=0, nu
                 c.d_gains[i] = cfg.control.damping[key]
         c.torque_limits[i] = model.effort_limit[i]
         c.dof_vel_limits[i] = model.vel_limit[i]
-        lo, hi = np.float32(model.q_lo[i]), np.float32(model.q_hi[i])
+        lo, hi = np.float32(info["q_lo_raw"][i]), np.float32(info["q_hi_raw"][i])
         mid, rng = (lo + hi) / np.float32(2), hi - lo
         c.dof_pos_soft_lo[i] = mid - np.float32(0.5) * rng * np.float32(cfg.rewards.soft_dof_pos_limit)
         c.dof_pos_soft_hi[i] = mid + np.float32(0.5) * rng * np.float32(cfg.rewards.soft_dof_pos_limit)
@@ -189,7 +212,7 @@ def build_config(cfg, model, info, sim_params, num_envs, *, env_index_base=0, nu
     c.obs_scale_lin_vel, c.obs_scale_ang_vel = sc.lin_vel, sc.ang_vel
     c.obs_scale_dof_pos, c.obs_scale_dof_vel, c.obs_scale_height = sc.dof_pos, sc.dof_vel, sc.height_measurements
     c.commands_scale[0], c.commands_scale[1], c.commands_scale[2] = sc.lin_vel, sc.lin_vel, sc.ang_vel
-    vec, priv = noise_scale_vec(cfg, nd)
+    vec, priv = noise_scale_vec(cfg, nd, kind)
     for i, v in enumerate(vec):
         c.obs_noise_vec[i] = v
     c.priv_height_noise = float(priv[0]) if (priv is not None and len(priv) and c.measure_heights) else 0.0
@@ -217,6 +240,13 @@ def build_config(cfg, model, info, sim_params, num_envs, *, env_index_base=0, nu
     c.max_depenetration_vel = px_.max_depenetration_velocity
     c.solver_iterations = px_.num_position_iterations
     c.seed_lo, c.seed_hi = seed & 0xFFFFFFFF, 0x9E3779B9
+    if LR:      # legged_robot.py:323, 343-349, 417; anymal.py:52
+        c.resample_interval = int(cfg.commands.resampling_time / dt)
+        rg = cfg.commands.ranges
+        for i, key in enumerate(("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")):
+            c.cmd_lo[i], c.cmd_hi[i] = getattr(rg, key)
+        c.max_push_vel = cfg.domain_rand.max_push_vel_xy
+        c.use_actuator_net = int(bool(getattr(cfg.control, "use_actuator_network", False)))
     return c, names
 
 

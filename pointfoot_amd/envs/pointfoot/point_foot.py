@@ -1,417 +1,9 @@
-"""`PointFoot` — host-side mirror of the reference env class (legged_gym/envs/pointfoot/point_foot.py:16-1253).
-
-Same constructor, attributes and VecEnv protocol; everything that runs per step is ONE launch
-of the fused HIP kernel behind `pf_step` (include/pointfoot_hip.h).  Torch owns the memory: the per-env state
-is a single (N, rec) float32 tensor and `root_states`, `dof_pos`, `commands`, ... are live strided views into
-it, so scripts can read and write them exactly like the reference's wrapped sim tensors.
-
-Deliberate divergences: the device argument is honoured (the reference forces CPU, :41,50-51);
-no `torch.save` side effect in `_add_noise_to_obs` (:334); no viewer.  There is NO CPU fallback: without the
-HIP library / a GPU the constructor raises.
-"""
-import ctypes as C
-import os
-
-import numpy as np
-import torch
-
+"""`PointFoot` — mirror of the reference env class legged_gym/envs/pointfoot/point_foot.py:16-1253 (PF_P441A biped).
+All machinery lives in `HipEnv`; this class fixes the env kind: 27-dim proprioceptive obs + 27/148-dim privileged obs,
+19-term reward stack, feet-state machine, force pushes, commands that never resample."""
 from pointfoot_amd import _abi
-from pointfoot_amd.envs.pointfoot import _native
-from pointfoot_amd.utils.terrain import Terrain
+from pointfoot_amd.envs.base.hip_env import HipEnv
 
 
-class _EpisodeInfo(dict):
-    """extras["episode"] (reference :276-285): `rew_<name>` = mean(episode_sums[reset ids]) / max_episode_length_s and
-    `terrain_level`, as 0-d device tensors.  Filled lazily from the step's statistics slot on first access, so a
-    rollout that nobody logs costs no extra kernels and nothing ever synchronises with the host."""
-
-    def __init__(self, fill):
-        super().__init__()
-        self._fill = fill
-
-    def _ensure(self):
-        if self._fill is not None:
-            f, self._fill = self._fill, None
-            super().update(f())
-
-    def __getitem__(self, k):
-        self._ensure(); return super().__getitem__(k)
-
-    def __iter__(self):
-        self._ensure(); return super().__iter__()
-
-    def __len__(self):
-        self._ensure(); return super().__len__()
-
-    def __contains__(self, k):
-        self._ensure(); return super().__contains__(k)
-
-    def keys(self):
-        self._ensure(); return super().keys()
-
-    def items(self):
-        self._ensure(); return super().items()
-
-    def values(self):
-        self._ensure(); return super().values()
-
-    def get(self, k, d=None):
-        self._ensure(); return super().get(k, d)
-
-    def __bool__(self):
-        return True
-
-
-class PointFoot:
-    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
-        self.terminate = None
-        self.cfg = cfg
-        self.sim_params = sim_params
-        self.height_samples = None
-        self.debug_viz = False
-        self.init_done = False
-        self._parse_cfg()
-        self.physics_engine = physics_engine
-        self.sim_device = sim_device
-        self.headless = headless
-        if not str(sim_device).startswith("cuda"):
-            raise RuntimeError(
-                f"PointFoot (pointfoot_amd) runs on the MI355X HIP kernel only; got sim_device={sim_device!r}. "
-                "The CPU restatement lives under oracle/ and is test infrastructure.")
-        if not torch.cuda.is_available():
-            raise RuntimeError("PointFoot (pointfoot_amd): no GPU visible and there is no CPU fallback")
-        self.device = sim_device
-        self._lib = _abi.load()
-        self.num_envs = cfg.env.num_envs
-        self.num_obs = cfg.env.num_propriceptive_obs
-        self.num_privileged_obs = cfg.env.num_privileged_obs
-        self.num_actions = cfg.env.num_actions
-        # multi-GPU sharding: rank r owns global envs [r*N, (r+1)*N)  
-        self.rank = int(os.environ.get("RANK", "0")) if getattr(cfg, "shard_envs", True) else 0
-        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if getattr(cfg, "shard_envs", True) else 1
-        self.extras = {}
-        self.viewer = None
-        self.enable_viewer_sync = True
-        self.create_sim()
-        self._include_feet_height_rewards = self._check_if_include_feet_height_rewards()
-        self._init_buffers()
-        self._prepare_reward_function()
-        self.init_done = True
-
-    # ------------------------------------------------------------------ reference-compatible hooks
-    def update_frictions(self, fric, env_handle=0, actor_handle=0):
-        """reference :103-108 sets DOF friction via gym; here: the env's shape friction coefficient."""
-        v = float(np.mean(np.asarray(fric, dtype=np.float64)))
-        self._state[int(env_handle), self._L.friction] = v
-
-    def update_added_mass_and_base_com(self, added_mass, added_com, env_handle=0, actor_handle=0):
-        """reference :110-121"""
-        i = int(env_handle)
-        self._state[i, self._L.added_mass] += float(added_mass)
-        for k in range(3):
-            self._state[i, self._L.added_com + k] += float(added_com[k])
-        self.base_mass[i] = self._model_info["base_mass"] + self._state[i, self._L.added_mass]
-
-    def update_cmd(self, cmd):
-        """reference :123-129"""
-        self.commands[0][0] = cmd[0]
-        self.commands[0][1] = cmd[1]
-        self.commands[0][2] = cmd[2]
-        self.compute_observations()
-
-    def get_observations(self):
-        return self.proprioceptive_obs_buf
-
-    def get_privileged_observations(self):
-        return self.privileged_obs_buf
-
-    def set_camera(self, position, lookat):
-        pass    # headless only
-
-    def render(self, sync_frame_time=True):
-        pass
-
-    @property
-    def episode_length_buf(self):
-        return self._episode_length_buf
-
-    @episode_length_buf.setter
-    def episode_length_buf(self, value):
-        # the runner ASSIGNS a new tensor (random episode start); keep the kernel's buffer, copy the values in
-        self._episode_length_buf.copy_(torch.as_tensor(value).to(self._episode_length_buf.device, torch.int64))
-
-    # ------------------------------------------------------------------ VecEnv protocol
-    def reset(self):
-        """reference :137-142: reset_idx(all) then one zero-action step."""
-        self.reset_idx(torch.arange(self.num_envs, device=self.device))
-        obs, privileged_obs, _, _, _ = self.step(
-            torch.zeros(self.num_envs, self.num_actions, device=self.device, requires_grad=False))
-        return obs, privileged_obs
-
-    def step(self, actions):
-        """reference :170-193 — one fused kernel launch."""
-        a = actions.detach().to(device=self.device, dtype=torch.float32).contiguous()
-        self.common_step_counter += 1
-        self._next_stats_slot()
-        _abi.check(self._lib.pf_step(self._h, a.data_ptr(), self.common_step_counter, None, self._stream()), self._lib)
-        self._fill_extras()
-        return self.proprioceptive_obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
-
-    def step_injected(self, actions, inject):
-        """parity-test entry: same launch with an injected PfInject (sim snapshot and/or random numbers)."""
-        a = actions.detach().to(device=self.device, dtype=torch.float32).contiguous()
-        self.common_step_counter += 1
-        self._next_stats_slot()
-        _abi.check(self._lib.pf_step(self._h, a.data_ptr(), self.common_step_counter, C.byref(inject), self._stream()), self._lib)
-        self._fill_extras()
-        return self.proprioceptive_obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
-
-    def reset_idx(self, env_ids):
-        """reference :249-288.  The per-step masked reset happens inside the kernel; this host entry serves
-        `reset()` (all envs) and scripted partial resets."""
-        if len(env_ids) == 0:
-            return
-        if len(env_ids) == self.num_envs:
-            _abi.check(self._lib.pf_reset_all(self._h, self.common_step_counter, None, self._stream()), self._lib)
-            self._fill_extras()
-            return
-        raise NotImplementedError("host-side partial reset_idx: resets are taken by the step kernel (masked, in place)")
-
-    def compute_observations(self):
-        _abi.check(self._lib.pf_compute_observations(self._h, self.common_step_counter, None, self._stream()), self._lib)
-
-    def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-
-    def _next_stats_slot(self):
-        """rotate the per-step statistics slot (ring of 64: valid for the iteration the runner logs)"""
-        self._stats_slot = (self._stats_slot + 1) % self._stats_ring.shape[0]
-        self._reset_stats = self._stats_ring[self._stats_slot]
-        _abi.check(self._lib.pf_set_reset_stats(self._h, self._reset_stats.data_ptr()), self._lib)
-
-    def _fill_extras(self):
-        # reference :276-288
-        stats, names, T = self._reset_stats, self._sum_names, self.max_episode_length_s
-        curriculum, levels = self.cfg.terrain.curriculum, self.terrain_levels
-
-        def fill():
-            cnt = stats[_abi.PF_MAX_REWARDS].clamp(min=1.0)
-            vals = stats[:len(names)] / cnt / T
-            ep = {'rew_' + k: vals[i] for i, k in enumerate(names)}
-            if curriculum:
-                ep["terrain_level"] = torch.mean(levels.float())
-            if self.cfg.commands.curriculum:
-                ep["max_command_x"] = self.command_ranges["lin_vel_x"][1]
-            return ep
-        self.extras["episode"] = _EpisodeInfo(fill)
-        if self.cfg.env.send_timeouts:
-            self.extras["time_outs"] = self.time_out_buf
-
-    # ------------------------------------------------------------------ construction
-    def _parse_cfg(self):
-        """reference :999-1009"""
-        from pointfoot_amd.utils.helpers import class_to_dict
-        self.dt = self.cfg.control.decimation * self.sim_params.dt
-        self.obs_scales = self.cfg.normalization.obs_scales
-        self.reward_scales = class_to_dict(self.cfg.rewards.scales)
-        self.command_ranges = class_to_dict(self.cfg.commands.ranges)
-        if self.cfg.terrain.mesh_type not in ['heightfield', 'trimesh']:
-            self.cfg.terrain.curriculum = False
-        self.max_episode_length_s = self.cfg.env.episode_length_s
-        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
-        self.cfg.domain_rand.push_interval = np.ceil(self.cfg.domain_rand.push_interval_s / self.dt)
-
-    def _check_if_include_feet_height_rewards(self):
-        return any("feet_height" in s for s in dir(self.cfg.rewards.scales) if not s.startswith("__"))
-
-    def create_sim(self):
-        """reference :384-401 (+ _create_envs :870-968): terrain, robot model, per-env randomisation."""
-        self.up_axis_idx = 2
-        mesh_type = self.cfg.terrain.mesh_type
-        if mesh_type in ['heightfield', 'trimesh']:
-            self.terrain = Terrain(self.cfg.terrain, self.num_envs)
-            self.height_samples = torch.tensor(self.terrain.heightsamples).view(
-                self.terrain.tot_rows, self.terrain.tot_cols).to(self.device).contiguous()
-        elif mesh_type not in (None, 'plane'):
-            raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
-        self._model, self._model_info = _native.build_model(self.cfg)
-        self.num_dof = self.num_dofs = self._model.nd
-        self.num_bodies = self._model.nb
-        self.dof_names = self._model_info["dof_names"]
-        mi = self._model_info
-        dev = self.device
-        self.feet_indices = torch.tensor(mi["feet_indices"], dtype=torch.long, device=dev)
-        self.penalised_contact_indices = torch.tensor(mi["penalised_contact_indices"], dtype=torch.long, device=dev)
-        self.termination_contact_indices = torch.tensor(mi["termination_contact_indices"], dtype=torch.long, device=dev)
-        bis = self.cfg.init_state.pos + self.cfg.init_state.rot + self.cfg.init_state.lin_vel + self.cfg.init_state.ang_vel
-        self.base_init_state = torch.tensor(bis, dtype=torch.float, device=dev)
-        self._get_env_origins()
-        N = self.num_envs
-        # domain randomisation (reference :423-434, :466-477); numpy draws follow the reference's per-env order
-        gen = torch.Generator().manual_seed(int(getattr(self.cfg, "seed", 1)) + 7919 * self.rank)
-        if self.cfg.domain_rand.randomize_friction:
-            lo, hi = self.cfg.domain_rand.friction_range
-            bucket_ids = torch.randint(0, 64, (N, 1), generator=gen)
-            buckets = (hi - lo) * torch.rand(64, 1, generator=gen) + lo
-            self.friction_coeffs = buckets[bucket_ids].view(N)
-        else:
-            self.friction_coeffs = torch.ones(N)      # asset default shape friction
-        added_mass = np.zeros(N)
-        added_com = np.zeros((N, 3))
-        dr = self.cfg.domain_rand
-        rm, rc = getattr(dr, "randomize_base_mass", False), getattr(dr, "randomize_base_com", False)
-        if rm or rc:
-            ncol = (1 if rm else 0) + (3 if rc else 0)
-            # single process: numpy's global stream, consumed per env like the reference; shards: a per-rank stream
-            rs = np.random if self.world_size == 1 else np.random.RandomState(int(getattr(self.cfg, "seed", 1)) + 1009 * (self.rank + 1))
-            u = rs.uniform(0.0, 1.0, (N, ncol))
-            k = 0
-            if rm:
-                a, b = dr.added_mass_range
-                added_mass = a + (b - a) * u[:, 0]
-                k = 1
-            if rc:
-                cv = np.asarray(dr.rand_com_vec, dtype=np.float64)
-                added_com = -cv + 2 * cv * u[:, k:k + 3]
-        self._added_mass, self._added_com = added_mass, added_com
-        self.base_mass = torch.tensor(mi["base_mass"] + added_mass, dtype=torch.float, device=dev)
-        self.envs = list(range(N))
-        self.actor_handles = [0] * N
-
-    def _get_env_origins(self):
-        """reference :970-997"""
-        N, dev = self.num_envs, self.device
-        if self.cfg.terrain.mesh_type in ["heightfield", "trimesh"]:
-            self.custom_origins = True
-            max_init_level = self.cfg.terrain.max_init_terrain_level
-            if not self.cfg.terrain.curriculum:
-                max_init_level = self.cfg.terrain.num_rows - 1
-            gen = torch.Generator().manual_seed(int(getattr(self.cfg, "seed", 1)) + 104729 * (self.rank + 1))
-            self.terrain_levels = torch.randint(0, max_init_level + 1, (N,), generator=gen).to(torch.int32).to(dev)
-            # terrain type from the GLOBAL env index so the curriculum mix matches one process with all envs
-            gidx = torch.arange(N) + self.rank * N
-            self.terrain_types = torch.div(gidx, (N * self.world_size / self.cfg.terrain.num_cols),
-                                           rounding_mode='floor').to(torch.int32).to(dev)
-            self.max_terrain_level = self.cfg.terrain.num_rows
-            self.terrain_origins = torch.from_numpy(self.terrain.env_origins).to(dev).to(torch.float).contiguous()
-            self._init_origins = self.terrain_origins[self.terrain_levels.long(), self.terrain_types.long()]
-        else:
-            self.custom_origins = False
-            self.terrain_levels = torch.zeros(N, dtype=torch.int32, device=dev)
-            self.terrain_types = torch.zeros(N, dtype=torch.int32, device=dev)
-            self.terrain_origins = None
-            num_cols = np.floor(np.sqrt(N))
-            num_rows = np.ceil(N / num_cols)
-            xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
-            spacing = self.cfg.env.env_spacing
-            o = torch.zeros(N, 3)
-            o[:, 0] = spacing * xx.flatten()[:N]
-            o[:, 1] = spacing * yy.flatten()[:N]
-            self._init_origins = o.to(dev)
-
-    def _init_buffers(self):
-        """reference :698-794 — allocate the kernel's buffers and expose the reference's attribute names as views."""
-        N, dev, lib = self.num_envs, self.device, self._lib
-        hf_shape = tuple(self.height_samples.shape) if self.height_samples is not None else None
-        self._cfg_c, self._sum_names = _native.build_config(
-            self.cfg, self._model, self._model_info, self.sim_params, N,
-            env_index_base=self.rank * N, num_envs_global=N * self.world_size, hf_shape=hf_shape,
-            mean_base_mass=float(self.base_mass.mean().item()), seed=int(getattr(self.cfg, "seed", 1)))
-        if "termination" in self.reward_scales and self.reward_scales["termination"] != 0:
-            self._sum_names = self._sum_names + ["termination"]
-        self._L = L = _abi.PfLayout()
-        _abi.check(lib.pf_layout(C.byref(self._model), C.byref(self._cfg_c), C.byref(L)), lib)
-        self._state = st = torch.zeros(N, L.rec_floats, dtype=torch.float32, device=dev)
-
-        def view(off, n):
-            return st[:, off:off + n]
-        nd, nb, nf = self.num_dof, self.num_bodies, self._model.nfeet
-        self.root_states = view(L.root, 13)
-        self.dof_pos, self.dof_vel = view(L.dof_pos, nd), view(L.dof_vel, nd)
-        self.base_quat = self.root_states[:, 3:7]
-        self.actions, self.last_actions = view(L.actions, self.num_actions), view(L.last_actions, self.num_actions)
-        self.last_dof_vel, self.last_root_vel = view(L.last_dof_vel, nd), view(L.last_root_vel, 6)
-        self.commands = view(L.commands, self.cfg.commands.num_commands)
-        self.torques = view(L.torques, nd)
-        self.base_lin_vel, self.base_ang_vel = view(L.base_lin_vel, 3), view(L.base_ang_vel, 3)
-        self.projected_gravity = view(L.projected_gravity, 3)
-        self.feet_air_time, self.last_feet_air_time = view(L.feet_air_time, nf), view(L.last_feet_air_time, nf)
-        self.current_max_feet_height = view(L.cur_max_feet_height, nf)
-        self.last_max_feet_height, self.feet_height = view(L.last_max_feet_height, nf), view(L.feet_height, nf)
-        self.contact_filt, self.first_contact = view(L.contact_filt, nf), view(L.first_contact, nf)   # 0/1 floats
-        self.last_contacts = view(L.last_contacts, nf)
-        self.contact_forces = view(L.contact_forces, 3 * nb).unflatten(1, (nb, 3))
-        self.feet_pos = view(L.feet_pos, 3 * nf).unflatten(1, (nf, 3))
-        self.rigid_body_external_forces = view(L.ext_force, 3)
-        self.env_origins = view(L.env_origin, 3)
-        self.episode_sums = {k: st[:, L.episode_sums + i] for i, k in enumerate(self._sum_names)}
-        # initial state: spawn pose (reference :932-937 spawns at origin + U(-1,1) xy; the runner resets at once)
-        self.env_origins[:] = self._init_origins
-        self.root_states[:] = self.base_init_state
-        self.root_states[:, :3] += self._init_origins
-        st[:, L.friction] = self.friction_coeffs.to(dev)
-        st[:, L.added_mass] = torch.tensor(self._added_mass, dtype=torch.float, device=dev)
-        st[:, L.added_com:L.added_com + 3] = torch.tensor(self._added_com, dtype=torch.float, device=dev)
-        self.dof_pos[:] = torch.tensor([self._cfg_c.default_dof_pos[i] for i in range(nd)], device=dev)
-        # plain buffers
-        self.proprioceptive_obs_buf = torch.zeros(N, self.num_obs, device=dev, dtype=torch.float)
-        self.privileged_obs_buf = (torch.zeros(N, self.num_privileged_obs, device=dev, dtype=torch.float)
-                                   if self.num_privileged_obs is not None else None)
-        self.rew_buf = torch.zeros(N, device=dev, dtype=torch.float)
-        self.reset_buf = torch.ones(N, device=dev, dtype=torch.bool)
-        self.time_out_buf = torch.zeros(N, device=dev, dtype=torch.bool)
-        self.terminate = torch.zeros(N, device=dev, dtype=torch.bool)
-        self._episode_length_buf = torch.zeros(N, device=dev, dtype=torch.long)
-        H = self._cfg_c.num_height_points
-        self.measured_heights = torch.zeros(N, H, device=dev, dtype=torch.float) if H else 0
-        self._stats_ring = torch.zeros(64, _abi.PF_STATS_FLOATS, device=dev, dtype=torch.float)
-        self._stats_slot = 0
-        self._reset_stats = self._stats_ring[0]
-        self.common_step_counter = 0
-        self.extras = {}
-        self.noise_scale_vec = tuple(None if v is None else torch.tensor(v, device=dev)
-                                     for v in _native.noise_scale_vec(self.cfg, nd))
-        self.add_noise = self.cfg.noise.add_noise
-        self.gravity_vec = torch.tensor([0., 0., -1.], device=dev).repeat((N, 1))
-        self.forward_vec = torch.tensor([1., 0., 0.], device=dev).repeat((N, 1))
-        c = self._cfg_c
-        self.p_gains = torch.tensor([c.p_gains[i] for i in range(nd)], device=dev)
-        self.d_gains = torch.tensor([c.d_gains[i] for i in range(nd)], device=dev)
-        self.torque_limits = torch.tensor([c.torque_limits[i] for i in range(nd)], device=dev)
-        self.dof_vel_limits = torch.tensor([c.dof_vel_limits[i] for i in range(nd)], device=dev)
-        self.dof_pos_limits = torch.tensor([[c.dof_pos_soft_lo[i], c.dof_pos_soft_hi[i]] for i in range(nd)], device=dev)
-        self.default_dof_pos = torch.tensor([c.default_dof_pos[i] for i in range(nd)], device=dev).unsqueeze(0)
-        self.commands_scale = torch.tensor([c.commands_scale[i] for i in range(3)], device=dev)
-        # native handle
-        self._h = lib.pf_create(C.byref(self._model), C.byref(c), torch.device(dev).index or 0)
-        if not self._h:
-            raise RuntimeError("pf_create failed: " + lib.pf_last_error().decode())
-        b = _abi.PfBuffers()
-        p = _native.ptr
-        b.d_state, b.d_episode_length = p(st), p(self._episode_length_buf)
-        b.d_terrain_level, b.d_terrain_type = p(self.terrain_levels), p(self.terrain_types)
-        b.d_reset, b.d_time_out, b.d_terminate = p(self.reset_buf), p(self.time_out_buf), p(self.terminate)
-        b.d_obs, b.d_priv, b.d_rew = p(self.proprioceptive_obs_buf), p(self.privileged_obs_buf), p(self.rew_buf)
-        b.d_measured_heights = p(self.measured_heights if H else None)
-        b.d_height_samples = p(self.height_samples)
-        b.d_terrain_origins = p(self.terrain_origins)
-        b.d_reset_stats = p(self._reset_stats)
-        self._bufs = b
-        _abi.check(lib.pf_bind_buffers(self._h, C.byref(b)), lib)
-
-    def _prepare_reward_function(self):
-        """reference :796-820 — names/scales only; the terms themselves are evaluated inside the kernel."""
-        for key in list(self.reward_scales.keys()):
-            if self.reward_scales[key] == 0:
-                self.reward_scales.pop(key)
-            else:
-                self.reward_scales[key] *= self.dt
-        self.reward_names = [n for n in self.reward_scales if n != "termination"]
-
-    def __del__(self):
-        try:
-            if getattr(self, "_h", None):
-                self._lib.pf_destroy(self._h)
-                self._h = None
-        except Exception:
-            pass
+class PointFoot(HipEnv):
+    KIND = _abi.PF_KIND_POINTFOOT

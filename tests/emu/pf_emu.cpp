@@ -7,15 +7,20 @@
 
 extern "C" int pfe_step(const PfModel* model, const PfConfig* cfg, const PfLayout* layout, const PfBuffers* bufs,
                         const float* actions, long long step_counter, const PfInject* inject, int mode) {
-  if (!(model->nb == 9 && model->nd == 6 && model->nfeet == 2)) return 1;
-  using K = PfKernel<9, 6, 2>;
-  static K::Shared sh;
   PfStepArgs g;
   g.model = model; g.cfg = cfg; g.L = *layout; g.b = *bufs;
   if (inject) g.inj = *inject; else std::memset(&g.inj, 0, sizeof(g.inj));
   g.actions = actions; g.step_counter = step_counter; g.mode = mode; g.stamps = nullptr;
   if (bufs->d_reset_stats && mode != 2) std::memset(bufs->d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS);
-  for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, g, env);
+  if (cfg->env_kind == PF_KIND_POINTFOOT && model->nb == 9 && model->nd == 6 && model->nfeet == 2) {
+    using K = PfKernel<9, 6, 2, PF_KIND_POINTFOOT>;
+    static K::Shared sh;
+    for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, g, env);
+  } else if (cfg->env_kind == PF_KIND_LEGGED_ROBOT && model->nb == 17 && model->nd == 12 && model->nfeet == 4) {
+    using K = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT>;
+    static K::Shared sh;
+    for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, g, env);
+  } else return 1;
   return 0;
 }
 extern "C" int pfe_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out) { return pf_compute_layout(model, cfg, out); }

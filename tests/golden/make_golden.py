@@ -165,7 +165,8 @@ class FakeGym:
         e = self.env
         e.root_states.copy_(torch.from_numpy(self.post["root"]))
         e.contact_forces.copy_(torch.from_numpy(self.post["contact"]))
-        e.rigid_body_states.copy_(torch.from_numpy(self.post["body"]))
+        if "body" in self.post:
+            e.rigid_body_states.copy_(torch.from_numpy(self.post["body"]))
 
 
 BODY_NAMES = ["base_Link", "abad_L_Link", "hip_L_Link", "knee_L_Link", "foot_L_Link",
@@ -472,6 +473,189 @@ def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at
     return out
 
 
+# ----------------------------------------------------------------------------- LeggedRobot (anymal_c_rough) golden
+def build_env_lr(n, rng_seed, model):
+    """Construct the reference LeggedRobot (legged_gym/envs/base/legged_robot.py) with the anymal_c_rough config, bypassing
+    the Isaac-Gym-bound constructors.  `model` = body/dof names of the collapsed ANYmal-C tree (pointfoot_amd URDF parser)."""
+    from legged_gym.envs.base.legged_robot import LeggedRobot
+    from legged_gym.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
+    cfg = AnymalCRoughCfg()
+    cfg.env.num_envs = n
+    e = object.__new__(LeggedRobot)
+    e.cfg = cfg
+    e.sim_params = types.SimpleNamespace(dt=cfg.sim.dt, use_gpu_pipeline=False)
+    e.height_samples = None
+    e.debug_viz = False
+    e.init_done = False
+    e._parse_cfg(cfg)
+    e.gym = FakeGym(); e.gym.env = e
+    e.sim = None; e.physics_engine = None; e.sim_device = "cpu"; e.headless = True; e.device = "cpu"
+    e.num_envs, e.num_obs, e.num_privileged_obs, e.num_actions = n, cfg.env.num_observations, cfg.env.num_privileged_obs, cfg.env.num_actions
+    e.obs_buf = torch.zeros(n, e.num_obs)
+    e.rew_buf = torch.zeros(n)
+    e.reset_buf = torch.ones(n, dtype=torch.long)
+    e.episode_length_buf = torch.zeros(n, dtype=torch.long)
+    e.time_out_buf = torch.zeros(n, dtype=torch.bool)
+    e.privileged_obs_buf = None
+    e.extras = {}
+    e.viewer = None; e.enable_viewer_sync = True; e.up_axis_idx = 2
+    bn, dn = model["body_names"], model["dof_names"]
+    e.num_dof = e.num_dofs = len(dn); e.num_bodies = len(bn); e.dof_names = dn
+    feet = [i for i, s in enumerate(bn) if cfg.asset.foot_name in s]
+    pen, term = [], []
+    for name in cfg.asset.penalize_contacts_on:
+        pen.extend([i for i, s in enumerate(bn) if name in s])
+    for name in cfg.asset.terminate_after_contacts_on:
+        term.extend([i for i, s in enumerate(bn) if name in s])
+    e.feet_indices = torch.tensor(feet, dtype=torch.long)
+    e.penalised_contact_indices = torch.tensor(pen, dtype=torch.long)
+    e.termination_contact_indices = torch.tensor(term, dtype=torch.long)
+    bis = cfg.init_state.pos + cfg.init_state.rot + cfg.init_state.lin_vel + cfg.init_state.ang_vel
+    e.base_init_state = torch.tensor(bis, dtype=torch.float)
+    nd = len(dn)
+    e.dof_pos_limits = torch.zeros(nd, 2); e.dof_vel_limits = torch.zeros(nd); e.torque_limits = torch.zeros(nd)
+    for i in range(nd):      # _process_dof_props for env 0 (legged_robot.py:286-305)
+        e.dof_pos_limits[i, 0] = model["q_lo"][i]; e.dof_pos_limits[i, 1] = model["q_hi"][i]
+        e.dof_vel_limits[i] = model["vel_limit"][i]; e.torque_limits[i] = model["effort_limit"][i]
+        m = (e.dof_pos_limits[i, 0] + e.dof_pos_limits[i, 1]) / 2
+        r = e.dof_pos_limits[i, 1] - e.dof_pos_limits[i, 0]
+        e.dof_pos_limits[i, 0] = m - 0.5 * r * cfg.rewards.soft_dof_pos_limit
+        e.dof_pos_limits[i, 1] = m + 0.5 * r * cfg.rewards.soft_dof_pos_limit
+    nrs = np.random.RandomState(rng_seed + 100)
+    hf, to = synth.synth_heightfield(), synth.synth_terrain_origins()
+    e.terrain = types.SimpleNamespace(cfg=cfg.terrain, env_length=cfg.terrain.terrain_length, env_width=cfg.terrain.terrain_width, env_origins=to)
+    e.height_samples = torch.tensor(hf).view(synth.TOT_ROWS, synth.TOT_COLS)
+    e.custom_origins = True
+    e.terrain_levels = torch.from_numpy(nrs.randint(0, cfg.terrain.max_init_terrain_level + 1, n)).long()
+    e.terrain_levels[:3] = cfg.terrain.num_rows - 1
+    e.terrain_types = torch.div(torch.arange(n), (n / cfg.terrain.num_cols), rounding_mode="floor").to(torch.long)
+    e.max_terrain_level = cfg.terrain.num_rows
+    e.terrain_origins = torch.from_numpy(to).to(torch.float)
+    e.env_origins = torch.zeros(n, 3)
+    e.env_origins[:] = e.terrain_origins[e.terrain_levels, e.terrain_types]
+    e._t_root = torch.zeros(n, 13); e._t_root[:, 6] = 1.0
+    e._t_dof = torch.zeros(n * nd, 2)
+    e._t_contact = torch.zeros(n * len(bn), 3)
+    g = e.gym
+    g.acquire_actor_root_state_tensor = lambda sim: e._t_root
+    g.acquire_dof_state_tensor = lambda sim: e._t_dof
+    g.acquire_net_contact_force_tensor = lambda sim: e._t_contact
+    e._init_buffers()
+    e._prepare_reward_function()
+    e.init_done = True
+    return e, cfg, feet
+
+
+def run_sequence_lr(n, steps, seed, model):
+    e, cfg, feet = build_env_lr(n, seed, model)
+    nb, nd = len(model["body_names"]), len(model["dof_names"])
+    rl = RandLog(seed)
+    torch.rand = rl.rand; torch.rand_like = rl.rand_like; torch.randint_like = rl.randint_like
+    rs = np.random.RandomState(seed)
+    origins = e.env_origins.numpy().astype(np.float64)
+    s0 = synth.synth_sim_state(rs, n, nb, nd, origins, feet, True)
+    e.root_states.copy_(torch.from_numpy(s0["root"]))
+    e.dof_state.copy_(torch.from_numpy(s0["dof"].reshape(-1, 2)))
+    e.contact_forces.copy_(torch.from_numpy(s0["contact"]))
+    e.episode_length_buf = torch.from_numpy(rs.randint(0, 1000, n)).long()
+    e.episode_length_buf[n // 2: n // 2 + 3] = 1000           # time-outs on the first step
+    e.episode_length_buf[4:8] = 499                            # periodic command resampling at 500
+    e.common_step_counter = int(cfg.domain_rand.push_interval) - 2
+    e.commands[:, 0] = torch.from_numpy(rs.uniform(-1, 1, n)).float()
+    e.commands[:, 1] = torch.from_numpy(rs.uniform(-1, 1, n)).float()
+    e.commands[:, 3] = torch.from_numpy(rs.uniform(-3.14, 3.14, n)).float()
+    e.last_actions[:] = torch.from_numpy(rs.normal(0, 1, (n, nd))).float()
+    e.last_dof_vel[:] = torch.from_numpy(rs.normal(0, 3, (n, nd))).float()
+    e.feet_air_time[:] = torch.from_numpy(rs.uniform(0, 0.9, (n, 4))).float() * (torch.from_numpy(rs.uniform(size=(n, 4))) > 0.3)
+    e.last_contacts[:] = torch.from_numpy(rs.uniform(size=(n, 4)) > 0.5)
+    for k in e.episode_sums:
+        e.episode_sums[k][:] = torch.from_numpy(rs.normal(0, 1, n)).float()
+    names = list(e.reward_names)
+    out = dict(reward_names=np.array(names), reward_scales=np.array([e.reward_scales[k] for k in names], np.float64),
+               noise_scale_vec=e.noise_scale_vec.numpy(), p_gains=e.p_gains.numpy(), d_gains=e.d_gains.numpy(),
+               default_dof_pos=e.default_dof_pos.numpy().reshape(-1), terrain_types=e.terrain_types.numpy(),
+               terrain_origins=e.terrain_origins.numpy(), feet_indices=np.array(feet),
+               penalised_contact_indices=e.penalised_contact_indices.numpy(), termination_contact_indices=e.termination_contact_indices.numpy(),
+               push_interval=np.array(cfg.domain_rand.push_interval), max_episode_length=np.array(e.max_episode_length))
+
+    def snap(prefix):
+        d = dict(root=e.root_states.numpy().copy(), dof=e.dof_state.numpy().reshape(n, nd, 2).copy(),
+                 episode_length=e.episode_length_buf.numpy().copy(), commands=e.commands.numpy().copy(),
+                 last_actions=e.last_actions.numpy().copy(), last_dof_vel=e.last_dof_vel.numpy().copy(),
+                 feet_air_time=e.feet_air_time.numpy().copy(), last_contacts=e.last_contacts.numpy().copy(),
+                 episode_sums=np.stack([e.episode_sums[k].numpy() for k in names]).copy(), env_origins=e.env_origins.numpy().copy(),
+                 terrain_levels=e.terrain_levels.numpy().copy(), common_step_counter=np.array(e.common_step_counter))
+        return {f"{prefix}_{k}": v for k, v in d.items()}
+    out.update(snap("init"))
+    for t in range(steps):
+        acts = rs.normal(0, 1.0, (n, nd)).astype(np.float32)
+        subs = [synth.synth_sim_state(rs, n, nb, nd, origins, feet, True) for _ in range(4)]
+        if t == 1:
+            subs[3]["contact"][9:12, 0, :] = 7.0
+        e.gym.dof_queue = [s["dof"] for s in subs]
+        e.gym.post = dict(root=subs[3]["root"], contact=subs[3]["contact"])
+        ep_before = e.episode_length_buf.numpy().copy()
+        rl.take()
+        obs, priv, rew, reset, extras = e.step(torch.from_numpy(acts))
+        calls = rl.take()
+        ids = reset.nonzero(as_tuple=False).flatten().numpy()
+        rsm = np.nonzero((ep_before + 1) % int(cfg.commands.resampling_time / e.dt) == 0)[0]
+        ci = 0
+        r_cmd = np.zeros((n, 3), np.float32); r_cmd_reset = np.zeros((n, 3), np.float32)
+        for k in range(3):      # periodic resample: 3 draws of shape (len(rsm), 1), even when empty
+            kind, shape, tt = calls[ci]; ci += 1
+            assert kind == "rand" and shape == (len(rsm), 1), (kind, shape, len(rsm))
+            if len(rsm): r_cmd[rsm, k] = tt.numpy().reshape(-1)
+        pushed = cfg.domain_rand.push_robots and (e.common_step_counter % cfg.domain_rand.push_interval == 0)
+        r_push = np.zeros((n, 3), np.float32)
+        if pushed:
+            kind, shape, tt = calls[ci]; ci += 1
+            assert kind == "rand" and shape == (n, 2)
+            r_push[:, :2] = tt.numpy()
+        r_level = np.full((n,), -1, np.int64); r_dof = np.zeros((n, nd), np.float32)
+        r_xy = np.zeros((n, 2), np.float32); r_vel = np.zeros((n, 6), np.float32)
+        if len(ids):
+            kind, shape, tt = calls[ci]; ci += 1
+            assert kind == "randint_like" and shape == (len(ids),)
+            r_level[ids] = tt.numpy()
+            kind, shape, tt = calls[ci]; ci += 1
+            assert kind == "rand" and shape == (len(ids), nd)
+            r_dof = scatter_rows(n, ids, tt, nd)
+            kind, shape, tt = calls[ci]; ci += 1
+            assert kind == "rand" and shape == (len(ids), 2)
+            r_xy = scatter_rows(n, ids, tt, 2)
+            kind, shape, tt = calls[ci]; ci += 1
+            assert kind == "rand" and shape == (len(ids), 6)
+            r_vel = scatter_rows(n, ids, tt, 6)
+            for k in range(3):
+                kind, shape, tt = calls[ci]; ci += 1
+                assert kind == "rand" and shape == (len(ids), 1)
+                r_cmd_reset[ids, k] = tt.numpy().reshape(-1)
+        kind, shape, tt = calls[ci]; ci += 1
+        assert kind == "rand_like" and shape == (n, e.num_obs)
+        r_obs = tt.numpy().copy()
+        assert ci == len(calls), (ci, len(calls))
+        p = f"s{t}"
+        out.update({f"{p}_actions": acts, f"{p}_dof_pre": subs[2]["dof"], f"{p}_dof_post": subs[3]["dof"], f"{p}_sim_root": subs[3]["root"],
+                    f"{p}_sim_contact": subs[3]["contact"], f"{p}_r_cmd": r_cmd, f"{p}_r_cmd_reset": r_cmd_reset, f"{p}_r_push": r_push,
+                    f"{p}_r_level": r_level, f"{p}_r_dof": r_dof, f"{p}_r_xy": r_xy, f"{p}_r_vel": r_vel, f"{p}_r_obs": r_obs,
+                    f"{p}_pushed": np.array(bool(pushed)), f"{p}_obs": obs.numpy().copy(), f"{p}_rew": rew.numpy().copy(),
+                    f"{p}_reset": reset.numpy().copy(), f"{p}_time_out": e.time_out_buf.numpy().copy(), f"{p}_torques": e.torques.numpy().copy(),
+                    f"{p}_base_lin_vel": e.base_lin_vel.numpy().copy(), f"{p}_measured_heights": e.measured_heights.numpy().copy()})
+        if len(ids):
+            out[f"{p}_extras_rew"] = np.array([float(extras["episode"]["rew_" + k]) for k in e.episode_sums.keys()], np.float64)
+        out.update(snap(p))
+    torch.rand = _orig_rand
+    return out
+
+
+def anymal_model():
+    """ANYmal-C body / DOF tables from the reference URDF via this repo's parser (names and limits only are used here)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from pointfoot_amd.utils.urdf import parse_urdf
+    return parse_urdf(os.path.join(REF, "resources", "robots", "anymal_c", "urdf", "anymal_c.urdf"))
+
+
 def misc_vectors():
     from legged_gym.utils.math import wrap_to_pi, quat_apply_yaw
     rs = np.random.RandomState(5)
@@ -497,6 +681,10 @@ def main():
         np.savez_compressed(fn, **out)
         print("wrote", fn, os.path.getsize(fn), "bytes; rewards:", list(out["reward_names"]))
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc_vectors())
+    out = run_sequence_lr(32, 5, 6, anymal_model())
+    fn = os.path.join(HERE, "lr_anymal_c_rough_n32.npz")
+    np.savez_compressed(fn, **out)
+    print("wrote", fn, os.path.getsize(fn), "bytes; rewards:", list(out["reward_names"]))
 
 
 if __name__ == "__main__":

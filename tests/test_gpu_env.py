@@ -140,3 +140,56 @@ def test_hip_full_size_properties():
         assert (sim.terrain_level >= 0).all() and (sim.terrain_level < 10).all()
     assert np.isfinite(sim.state).all()
     hip.close(); hip2.close()
+
+
+# ------------------------------------------------------------------------------- LeggedRobot / Anymal variant (config 5 path)
+def test_hip_legged_robot_python_layer_matches_reference_golden():
+    from test_golden_legged_robot import lr_sim_from_golden, lr_inject, lr_check_step
+    g = common.load_golden("lr_anymal_c_rough_n32")
+    sim = lr_sim_from_golden(g)
+    hip = common.HipMirror(sim)
+    names = list(g["reward_names"])
+    counter = int(g["init_common_step_counter"])
+    keep = []
+    for t in range(5):
+        counter += 1
+        _, arrs = lr_inject(g, t, sim, keep)
+        hip.step(g[f"s{t}_actions"], counter, arrs)
+        lr_check_step(sim, g, t, names)
+    hip.close()
+
+
+def test_hip_anymal_full_step_matches_oracle():
+    """17-body/12-DOF instance, actuator-network torques, LeggedRobot python layer, Philox noise: HIP vs oracle."""
+    from test_golden_legged_robot import act_params
+    n = 128
+    cfg = common.make_cfg("anymal_c_flat", n, add_noise=True)
+    sim = common.HostSim(cfg, n, actuator=act_params())
+    sim.c.use_actuator_net = 1
+    rs = np.random.RandomState(2)
+    sim.f("root", 13)[:, 2] = 0.62
+    sim.f("root", 13)[:, 0:2] = rs.uniform(-2, 2, (n, 2))
+    sim.f("friction")[:] = rs.uniform(0.3, 1.2, n)
+    sim.f("added_mass")[:] = rs.uniform(-5, 5, n)
+    sim.f("dof_pos", 12)[:] = np.array([sim.c.default_dof_pos[i] for i in range(12)]) + rs.uniform(-0.05, 0.05, (n, 12))
+    sim.episode_length[:] = rs.randint(0, 990, n)
+    ref = sim.clone()
+    hip = common.HipMirror(sim)
+    bad = 0
+    for t in range(25):
+        act = rs.normal(0, 0.4, (n, 12)).astype(np.float32)
+        for k in common.HipMirror.FIELDS:
+            getattr(sim, k)[...] = getattr(ref, k)
+        hip.upload()
+        ref.step("oracle", act, t + 1)
+        hip.step(act, t + 1)
+        same = ref.reset == sim.reset
+        bad += int((~same).sum())
+        e_obs = np.abs(sim.obs[same] - ref.obs[same]).max(axis=1)
+        e_rew = np.abs(sim.rew[same] - ref.rew[same])
+        ok = (e_obs <= 1e-4) & (e_rew <= 1e-4 + 1e-4 * np.abs(ref.rew[same]))
+        assert ok.mean() >= 0.97, f"step {t}: {ok.mean():.3f} of envs within 1e-4 (max {e_obs.max():.2e})"
+        L = sim.L
+        np.testing.assert_allclose(sim.state[same][:, L.lstm_state:L.lstm_state + 384], ref.state[same][:, L.lstm_state:L.lstm_state + 384], atol=1e-4)
+    assert bad <= 3
+    hip.close()

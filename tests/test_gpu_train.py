@@ -98,3 +98,50 @@ def test_train_save_load_play_export(tmp_path):
     export_policy_as_jit(r2.alg.actor_critic, str(tmp_path / "exported"))
     jit = torch.jit.load(str(tmp_path / "exported" / "policy_1.pt"))
     torch.testing.assert_close(jit(obs.cpu()), a.cpu(), atol=2e-5, rtol=1e-5)
+
+
+def test_reference_test_env_and_play(tmp_path, monkeypatch):
+    """the reference's own smoke test (tests/test_env.py) and play.py flow on the GPU"""
+    import pointfoot_amd
+    from pointfoot_amd.tests.test_env import test_env
+    from pointfoot_amd.scripts import play as play_mod
+    from pointfoot_amd.envs import task_registry
+    env = test_env(_args("pointfoot_flat", 10), steps=300)
+    assert env.num_envs == 10
+    # train 2 iterations into <root>/logs/pointfoot_flat/..., then play from the checkpoint
+    monkeypatch.setattr(pointfoot_amd, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
+    import pointfoot_amd.utils.task_registry as tr
+    monkeypatch.setattr(tr, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
+    monkeypatch.setattr(play_mod, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
+    args = _args("pointfoot_flat", 64, ["--max_iterations", "2"])
+    env_cfg, train_cfg = task_registry.get_cfgs("pointfoot_flat")
+    saved = (env_cfg.env.num_envs, train_cfg.runner.resume, env_cfg.noise.add_noise, env_cfg.domain_rand.push_robots,
+             env_cfg.domain_rand.randomize_friction)
+    try:
+        e, _ = task_registry.make_env("pointfoot_flat", args=args)
+        r, _ = task_registry.make_alg_runner(e, "pointfoot_flat", args=args)
+        r.learn(2, init_at_random_ep_len=True)
+        played = play_mod.play(_args("pointfoot_flat", 64), num_steps=50)
+        assert played.num_envs == 50 and not played.cfg.noise.add_noise
+        assert (tmp_path / "logs" / "pointfoot_flat" / "exported" / "policies" / "policy_1.pt").exists()
+    finally:
+        env_cfg.env.num_envs, train_cfg.runner.resume, env_cfg.noise.add_noise, env_cfg.domain_rand.push_robots, \
+            env_cfg.domain_rand.randomize_friction = saved
+
+
+def test_anymal_c_flat_trains_through_registry():
+    """config-5 family on the GPU: Anymal (LeggedRobot + actuator net), 12 actions, 48-dim obs, critic = actor obs."""
+    from pointfoot_amd.envs import task_registry, Anymal
+    args = _args("anymal_c_flat", 128, ["--max_iterations", "3"])
+    env, cfg = task_registry.make_env("anymal_c_flat", args=args)
+    assert isinstance(env, Anymal) and env.num_obs == 48 and env.num_privileged_obs is None and env.num_actions == 12
+    assert env.privileged_obs_buf is None and env.obs_buf.shape == (128, 48)
+    assert env.sea_hidden_state_per_env.shape == (128, 12, 2, 8)
+    runner, _ = task_registry.make_alg_runner(env, "anymal_c_flat", args=args, log_root=None)
+    p0 = runner.alg.params.clone()
+    runner.learn(3, init_at_random_ep_len=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(runner.alg.params).all() and not torch.equal(p0, runner.alg.params)
+    obs, priv, rew, done, extras = env.step(torch.zeros(128, 12, device="cuda:0"))
+    assert priv is None and torch.isfinite(obs).all() and (rew >= 0).all()       # only_positive_rewards
+    assert "rew_feet_air_time" in extras["episode"] and "terrain_level" not in extras["episode"]
