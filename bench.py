@@ -184,31 +184,44 @@ def main():
     finite = bool(torch.isfinite(runner.alg.params).all().item()) and bool(torch.isfinite(env.rew_buf).all().item())
     if rank == 0:
         rough = "rough" in a.task
-        bytes_per_env = STEP_BYTES_PER_ENV if rough else 850
+        anymal = a.task.startswith("anymal")
+        ac = runner.alg.actor_critic
+        fwd_macs = sum(x * y for x, y in zip(ac.actor_dims[:-1], ac.actor_dims[1:])) + sum(x * y for x, y in zip(ac.critic_dims[:-1], ac.critic_dims[1:]))
+        upd_flop_per_env_step = 2.0 * fwd_macs * 3 * runner.alg.num_learning_epochs        # fwd + 2x bwd per epoch (SURVEY §8d accounting)
+        if anymal:
+            bytes_per_env = 5900 if rough else 3900          # anymal_c_rough ~5.9 KB/env-step
+        else:
+            bytes_per_env = STEP_BYTES_PER_ENV if rough else 850
         ach_gbs = bytes_per_env * a.num_envs / (step_ms * 1e-3) / 1e9
-        upd_flop = 12.5e6 * a.num_envs * T if rough else 0.88e6 * a.num_envs * T * (12.5 / 13.4)
+        upd_flop = upd_flop_per_env_step * a.num_envs * T
         ach_tf = upd_flop / (upd_ms * 1e-3) / 1e12
+        headline = a.task == "pointfoot_rough" and a.num_envs == NUM_ENVS
+        dims = lambda d: "-".join(str(v) for v in d)
+        kern = "pf_step_kernel<17,12,4,LeggedRobot>" if anymal else "pf_step_kernel<9,6,2,PointFoot>"
         out = {
-            "metric": "env-steps/sec (whole node), pointfoot_rough 4096 envs/GPU" if rough else f"env-steps/sec, {a.task}",
+            "metric": "env-steps/sec (whole node), pointfoot_rough 4096 envs/GPU" if headline else f"env-steps/sec (whole node), {a.task} {a.num_envs} envs/GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.task}: {a.num_envs} envs/GPU x {T} policy steps/iter (4 physics substeps each), "
-                                   f"curriculum height field 1300x2100 int16, 121-pt height scan, DR + noise + pushes; PPO 5 epochs x 4 "
-                                   f"minibatches of {a.num_envs * T // 4}, actor 27-512-256-128-6 / critic 148-512-256-128-1 (ELU), fp32",
+                                   + ("curriculum height field 1300x2100 int16, " + (f"{env._cfg_c.num_height_points}-pt height scan, ") if rough else "plane, ")
+                                   + f"DR + noise + pushes; PPO {runner.alg.num_learning_epochs} epochs x {runner.alg.num_mini_batches} "
+                                   f"minibatches of {a.num_envs * T // runner.alg.num_mini_batches}, actor {dims(ac.actor_dims)} / critic {dims(ac.critic_dims)} (ELU), fp32"
+                                   + (", ANYdrive actuator-network LSTM in the step kernel" if anymal else ""),
                        "parallelism": f"dp{n_gpus} (env shards, RCCL gradient all-reduce)" if n_gpus > 1 else "single GPU",
                        "finite": finite},
-            "roofline": {"kernel": "pf_step_kernel<9,6,2> (fused env step)", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": kern + " (fused env step)", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": STEP_TRAFFIC_BYTES_N4096_ROUGH if (rough and a.num_envs == 4096) else None,
+                         "traffic": STEP_TRAFFIC_BYTES_N4096_ROUGH if headline else None,
                          "launch_ms": step_ms, "bytes_per_launch": bytes_per_env * a.num_envs,
                          "note": "latency/occupancy-bound by construction (SURVEY §8d honesty note); launch_ms from HIP events on the launch stream"},
             "roofline_ppo": {"kernel": "pf_gemm_kernel (fp32 MFMA) inside the PPO update", "bound": "mfma", "achieved": ach_tf,
                              "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / MFMA_F32_PEAK_TFLOPS,
-                             "update_ms": upd_ms, "note": "GEMM flops of one update / event-timed duration of the whole update phase"},
+                             "update_ms": upd_ms, "flop_per_update": upd_flop,
+                             "note": "GEMM flops of one update / event-timed duration of the whole update phase"},
             "phase_ms": {"env_step_launch": step_ms, "ppo_update": upd_ms, "iteration": dt / a.steps * 1e3},
         }
-        if n_gpus == 1 and not a.no_cpu_baseline:
+        if n_gpus == 1 and not a.no_cpu_baseline and not anymal:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.task, a.num_envs, min(10, os.cpu_count() or 1))
             except Exception as ex:      # the baseline is informational; never lose the GPU measurement over it

@@ -321,7 +321,6 @@ class HipEnv:
             self.cfg, self._model, self._model_info, self.sim_params, N, kind=self.KIND,
             env_index_base=self.rank * N, num_envs_global=N * self.world_size, hf_shape=hf_shape,
             mean_base_mass=float(self.base_mass.mean().item()), seed=int(getattr(self.cfg, "seed", 1)))
-        self._load_actuator_network(dev)
         if "termination" in self.reward_scales and self.reward_scales["termination"] != 0:
             self._sum_names = self._sum_names + ["termination"]
         self._L = L = _abi.PfLayout()
@@ -389,6 +388,7 @@ class HipEnv:
         self.dof_pos_limits = torch.tensor([[c.dof_pos_soft_lo[i], c.dof_pos_soft_hi[i]] for i in range(nd)], device=dev)
         self.default_dof_pos = torch.tensor([c.default_dof_pos[i] for i in range(nd)], device=dev).unsqueeze(0)
         self.commands_scale = torch.tensor([c.commands_scale[i] for i in range(3)], device=dev)
+        self._load_actuator_network(dev)
         # native handle
         self._h = lib.pf_create(C.byref(self._model), C.byref(c), torch.device(dev).index or 0)
         if not self._h:

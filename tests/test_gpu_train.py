@@ -110,7 +110,8 @@ def test_reference_test_env_and_play(tmp_path, monkeypatch):
     assert env.num_envs == 10
     # train 2 iterations into <root>/logs/pointfoot_flat/..., then play from the checkpoint
     monkeypatch.setattr(pointfoot_amd, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
-    import pointfoot_amd.utils.task_registry as tr
+    import sys
+    tr = sys.modules["pointfoot_amd.utils.task_registry"]
     monkeypatch.setattr(tr, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
     monkeypatch.setattr(play_mod, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
     args = _args("pointfoot_flat", 64, ["--max_iterations", "2"])
@@ -121,7 +122,8 @@ def test_reference_test_env_and_play(tmp_path, monkeypatch):
         e, _ = task_registry.make_env("pointfoot_flat", args=args)
         r, _ = task_registry.make_alg_runner(e, "pointfoot_flat", args=args)
         r.learn(2, init_at_random_ep_len=True)
-        played = play_mod.play(_args("pointfoot_flat", 64), num_steps=50)
+        from pointfoot_amd.utils import get_args
+        played = play_mod.play(get_args(["--task", "pointfoot_flat", "--headless"]), num_steps=50)   # no --num_envs: play caps at 50
         assert played.num_envs == 50 and not played.cfg.noise.add_noise
         assert (tmp_path / "logs" / "pointfoot_flat" / "exported" / "policies" / "policy_1.pt").exists()
     finally:
