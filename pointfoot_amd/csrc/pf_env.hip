@@ -27,9 +27,9 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // touches its own record, so no inter-workgroup ordering is needed.
 // model / cfg are separate __restrict__ const kernel arguments so the compiler can prove they are invariant and
 // read them with scalar loads (s_load) into SGPRs instead of holding hundreds of config values in VGPRs.
-template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT>
+template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH>
 __global__ __launch_bounds__(64, WAVES) void pf_step_kernel(const PfModel* __restrict__ model, const PfConfig* __restrict__ cfg, PfStepArgs g) {
-  using K = PfKernel<NB, ND, NF, KIND>;
+  using K = PfKernel<NB, ND, NF, KIND, KS>;
   __shared__ typename K::Shared sh;
   g.model = model; g.cfg = cfg;
   K::run(sh, g, (int)blockIdx.x);
@@ -64,7 +64,8 @@ int pf_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out) {
   return 0;
 }
 
-// kernel instances built: PointFoot PF_P441A (9 bodies / 6 dofs / 2 feet) and LeggedRobot ANYmal-C (17 / 12 / 4)
+// kernel instances built: PointFoot PF_P441A (9 bodies / 6 dofs / 2 feet) and LeggedRobot quadrupeds with 3-DOF legs and
+// separate feet (17 / 12 / 4: ANYmal-C, ANYmal-B, A1)
 static int pf_instance(const PfModel* m, const PfConfig* c) {
   if (c->env_kind == PF_KIND_POINTFOOT && m->nb == 9 && m->nd == 6 && m->nfeet == 2) return 0;
   if (c->env_kind == PF_KIND_LEGGED_ROBOT && m->nb == 17 && m->nd == 12 && m->nfeet == 4) return 1;
@@ -77,7 +78,7 @@ static int pf_validate(const PfModel* m, const PfConfig* c) {
     return 1;
   }
   int want_obs = inst == 0 ? 9 + 3 * m->nd : 12 + 3 * m->nd + c->num_height_points;
-  if (m->nsph > PF_KSPH || c->num_obs > PF_MAX_OBS || c->num_height_points > PF_MAX_HPTS ||
+  if (m->nsph > (inst == 0 ? PF_KSPH : PF_KSPH_QUAD) || c->num_obs > PF_MAX_OBS || c->num_height_points > PF_MAX_HPTS ||
       c->num_rewards >= PF_MAX_REWARDS || c->num_actions != m->nd || c->num_obs != want_obs) {
     pf_set_error("pf_create: configuration outside the compiled limits");
     return 1;
@@ -96,7 +97,7 @@ PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device) {
   pf_compute_layout(model, cfg, &e->layout);
   e->instance = pf_instance(model, cfg);
   bool lay_ok = e->instance == 0 ? PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::layout_matches(e->layout)
-                                 : PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT>::layout_matches(e->layout);
+                                 : PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>::layout_matches(e->layout);
   if (!lay_ok) { pf_set_error("pf_create: record layout differs from the kernel's compile-time layout"); delete e; return nullptr; }
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&e->d_model, sizeof(PfModel)) != hipSuccess ||
       hipMalloc(&e->d_cfg, sizeof(PfConfig)) != hipSuccess ||
@@ -172,7 +173,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   // PF_STEP_WAVES selects the register budget variant (waves per SIMD the kernel is compiled for)
   static const int variant = [] { const char* v = getenv("PF_STEP_WAVES"); return v ? atoi(v) : 4; }();
   dim3 grid(e->cfg.num_envs), block(64);
-  if (e->instance == 1) hipLaunchKernelGGL((pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT>), grid, block, 0, s, e->d_model, e->d_cfg, g);
+  if (e->instance == 1) hipLaunchKernelGGL((pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>), grid, block, 0, s, e->d_model, e->d_cfg, g);
   else if (variant == 4) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 4>), grid, block, 0, s, e->d_model, e->d_cfg, g);
   else if (variant == 3) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 3>), grid, block, 0, s, e->d_model, e->d_cfg, g);
   else hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 2>), grid, block, 0, s, e->d_model, e->d_cfg, g);

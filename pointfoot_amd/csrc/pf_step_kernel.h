@@ -14,7 +14,8 @@
 #define PF_MAXC 6          /* contacts kept per robot (first active in sphere order: feet first) */
 #define PF_MAX_CHAINS 8
 #define PF_MAX_CHAIN_DEPTH 8
-#define PF_KSPH 24         /* collision spheres staged per robot by the kernel instances built so far */
+#define PF_KSPH 24         /* collision spheres staged per robot (PointFoot instance; the quadruped instance uses 32) */
+#define PF_KSPH_QUAD 32
 
 // ------------------------------------------------------------------------------------ small math
 PF_DEV float pf_clip(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -126,7 +127,7 @@ struct PfStepArgs {
   unsigned* stamps;       // diagnostic build only, else NULL
 };
 
-template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT>
+template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH>
 struct PfKernel {
   static constexpr bool LR = KIND == PF_KIND_LEGGED_ROBOT;      // LeggedRobot / Anymal semantics (legged_robot.py)
   static constexpr int REC_MAX = LR ? 704 : PF_REC_MAX;
@@ -174,8 +175,8 @@ struct PfKernel {
     float joint_pos[NB][3], joint_rot[NB][9], joint_axis[NB][3];
     float mass[NB], com[NB][3], inertia[NB][6];
     float q_lo[ND], q_hi[ND], vel_limit[ND];
-    int sph_body[PF_KSPH];
-    float sph_pos[PF_KSPH][3], sph_radius[PF_KSPH];
+    int sph_body[KS];
+    float sph_pos[KS][3], sph_radius[KS];
     // root-to-leaf chains (one lane walks one chain in forward kinematics) and per-body 'fixed rotation is identity' flags
     int nchain, chain_len[PF_MAX_CHAINS], chain[PF_MAX_CHAINS][PF_MAX_CHAIN_DEPTH], rot_ident[NB];
   };
@@ -201,8 +202,8 @@ struct PfKernel {
     float rb[NROWS], rAinv[NROWS], lam[NROWS];
     float cA[MAXC][9], cdir[MAXC][9];
     int cbody[MAXC], con_sph[MAXC], lim_dof[ND], lim_side[ND];
-    float sphx[PF_KSPH][3], sphn[PF_KSPH][3], sphd[PF_KSPH];
-    int sphact[PF_KSPH];
+    float sphx[KS][3], sphn[KS][3], sphd[KS];
+    int sphact[KS];
   };
   // the height scan (post-physics only) reuses the constraint-row storage (physics only)
   static_assert(NROWS * NVP >= PF_MAX_HPTS, "height scan does not fit the aliased row storage");
@@ -892,7 +893,7 @@ struct PfKernel {
       for (int t = 0; t < 6; ++t) ms.inertia[i][t] = gm.inertia[i][t];
     }
     PF_LANES(k, ND) { ms.body_of_dof[k] = gm.body_of_dof[k]; ms.q_lo[k] = gm.q_lo[k]; ms.q_hi[k] = gm.q_hi[k]; ms.vel_limit[k] = gm.vel_limit[k]; }
-    PF_LANES(s2, PF_KSPH) {
+    PF_LANES(s2, KS) {
       ms.sph_body[s2] = gm.sph_body[s2]; ms.sph_radius[s2] = gm.sph_radius[s2];
       for (int t = 0; t < 3; ++t) ms.sph_pos[s2][t] = gm.sph_pos[s2][t];
     }

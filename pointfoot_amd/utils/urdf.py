@@ -5,7 +5,8 @@ legged_gym/envs/pointfoot/point_foot.py:883-909 with the asset options of pointf
   `dont_collapse="true"`; inertias are combined with the parallel-axis theorem;
 * bodies and DOFs are numbered depth-first in URDF child order (Isaac Gym's convention, SURVEY App. C);
 * collision primitives become spheres for the sphere-vs-heightfield contact model: sphere -> itself,
-  cylinder (-> capsule, `replace_cylinder_with_capsule=True`) -> its two end spheres, box -> 8 corners (r=0).
+  cylinder (-> capsule, `replace_cylinder_with_capsule=True`) -> its two end spheres, box on the root link -> 8 corners
+  (r=0), box on a limb -> two spheres on its long axis.
 
 A parsed model can be saved as / loaded from a small JSON table so the package works without the URDF
 file (the GPU box has no /root/reference); `resources/robots/PF_P441A/model.json` was produced by
@@ -65,7 +66,7 @@ def _add_inertial(link, mass, com, I):
     link.mass, link.com = m, c
 
 
-def _collision_spheres(link_elem):
+def _collision_spheres(link_elem, is_root=True):
     out = []
     for col in link_elem.findall("collision"):
         p, R = _origin(col)
@@ -80,6 +81,15 @@ def _collision_spheres(link_elem):
             axis = R @ np.array([0.0, 0.0, 1.0])
             out.append((p + half * axis, rad))
             out.append((p - half * axis, rad))
+        elif g.find("box") is not None and not is_root:
+            # limb boxes: two spheres on the long axis, radius = half the middle dimension (capsule-like stand-in)
+            dims = _floats(g.find("box").get("size"))
+            order = np.argsort(dims)
+            rad = 0.5 * dims[order[1]]
+            axis = np.zeros(3); axis[order[2]] = 1.0
+            half = max(0.5 * dims[order[2]] - rad, 0.0)
+            out.append((p + R @ (half * axis), rad))
+            out.append((p - R @ (half * axis), rad))
         elif g.find("box") is not None:
             sx, sy, sz = _floats(g.find("box").get("size"))
             for dx in (-0.5, 0.5):
@@ -103,7 +113,6 @@ def parse_urdf(path, collapse_fixed_joints=True):
                           [float(it.get("ixy")), float(it.get("iyy")), float(it.get("iyz"))],
                           [float(it.get("ixz")), float(it.get("iyz")), float(it.get("izz"))]])
             _add_inertial(lk, mass, p, R @ I @ R.T)
-        lk.spheres = _collision_spheres(le)
         links[lk.name] = lk
     child_names = set()
     for je in root.findall("joint"):
@@ -123,6 +132,8 @@ def parse_urdf(path, collapse_fixed_joints=True):
         child_names.add(child)
     base = [n for n in links if n not in child_names]
     assert len(base) == 1, f"expected one root link, got {base}"
+    for le in root.findall("link"):
+        links[le.get("name")].spheres = _collision_spheres(le, is_root=(le.get("name") == base[0]))
 
     bodies, dofs = [], []
 

@@ -17,7 +17,7 @@ extern "C" int pfe_step(const PfModel* model, const PfConfig* cfg, const PfLayou
     static K::Shared sh;
     for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, g, env);
   } else if (cfg->env_kind == PF_KIND_LEGGED_ROBOT && model->nb == 17 && model->nd == 12 && model->nfeet == 4) {
-    using K = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT>;
+    using K = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>;
     static K::Shared sh;
     for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, g, env);
   } else return 1;

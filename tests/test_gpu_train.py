@@ -147,3 +147,19 @@ def test_anymal_c_flat_trains_through_registry():
     obs, priv, rew, done, extras = env.step(torch.zeros(128, 12, device="cuda:0"))
     assert priv is None and torch.isfinite(obs).all() and (rew >= 0).all()       # only_positive_rewards
     assert "rew_feet_air_time" in extras["episode"] and "terrain_level" not in extras["episode"]
+
+
+@pytest.mark.parametrize("task,obs", [("anymal_c_rough", 235), ("anymal_b", 235), ("a1", 235)])
+def test_quadruped_tasks_step_and_stand(task, obs):
+    """every registered LeggedRobot task builds through the registry and holds its default pose under zero actions"""
+    from pointfoot_amd.envs import task_registry
+    env, cfg = task_registry.make_env(task, args=_args(task, 200))
+    assert env.num_obs == obs and env.num_actions == 12 and env.num_bodies == 17
+    o, _ = env.reset()
+    for _ in range(50):
+        o, p, r, d, e = env.step(torch.zeros(200, 12, device="cuda:0"))
+    torch.cuda.synchronize()
+    assert p is None and torch.isfinite(o).all() and torch.isfinite(env._state).all()
+    assert float(d.float().mean()) < 0.2                       # not collapsing every step
+    z = (env.root_states[:, 2] - env.env_origins[:, 2])
+    assert float(z.median()) > 0.5 * cfg.init_state.pos[2]      # still standing on its legs

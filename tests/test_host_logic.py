@@ -37,7 +37,7 @@ def test_pf_layout_host_only_and_error_reporting():
 def test_registry_cli_and_config_mirrors(tmp_path):
     from pointfoot_amd.envs import task_registry, PointFoot, PointFootRoughCfg
     from pointfoot_amd.utils.helpers import get_args, class_to_dict, update_cfg_from_args, get_load_path, parse_sim_params
-    assert set(task_registry.task_classes) == {"pointfoot_rough", "pointfoot_flat", "anymal_c_rough", "anymal_c_flat"}
+    assert set(task_registry.task_classes) == {"pointfoot_rough", "pointfoot_flat", "anymal_c_rough", "anymal_c_flat", "anymal_b", "a1"}
     with pytest.raises(ValueError, match="was not registered"):
         task_registry.make_env("cassie", args=get_args([]))
     env_cfg, train_cfg = task_registry.get_cfgs("pointfoot_rough")

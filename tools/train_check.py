@@ -12,6 +12,7 @@ env, _ = task_registry.make_env(task, args=args)
 runner, _ = task_registry.make_alg_runner(env, task, args=args, log_root=None)
 runner.env.episode_length_buf = torch.randint_like(runner.env.episode_length_buf, high=int(runner.env.max_episode_length))
 obs, cobs = env.get_observations(), env.get_privileged_observations()
+cobs = cobs if cobs is not None else obs
 t0 = time.time()
 for it in range(iters):
     obs, cobs, _ = runner.rollout(obs, cobs)
