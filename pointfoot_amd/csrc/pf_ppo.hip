@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -381,7 +382,12 @@ struct PpoAlg {
   // workspace carve (floats)
   size_t w_xa, w_xc, w_act, w_oldlogp, w_oldmu, w_oldsig, w_adv, w_ret, w_oldval;
   size_t w_ha[PPO_MAX_LAYERS], w_hc[PPO_MAX_LAYERS];   // activations per layer output (last = head output)
-  size_t w_dmean, w_dvalue, w_g[2], w_slabs, w_partial, w_lastval, w_total;
+  size_t w_dmean, w_dvalue, w_g[2][PPO_MAX_LAYERS], w_slabs[2], w_partial, w_lastval, w_total;   // [0] actor / [1] critic scratch (run concurrently)
+  hipStream_t aux = nullptr;        // second stream: the critic network runs beside the actor network
+  hipStream_t side[2] = {nullptr, nullptr};   // per network: weight-gradient GEMMs + slab reduces run beside the data-gradient chain
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_side[2][PPO_MAX_LAYERS + 1] = {}, ev_side_done[2] = {nullptr, nullptr};
+  bool dual = true, use_side = false;
   int max_rows = 0, max_width = 0, splits = 0;
 };
 
@@ -430,9 +436,9 @@ static void ppo_plan(PpoAlg* a) {
   for (int i = 0; i < a->actor.nl; ++i) a->w_ha[i] = take(R * a->actor.l[i].out);
   for (int i = 0; i < a->critic.nl; ++i) a->w_hc[i] = take(R * a->critic.l[i].out);
   a->w_dmean = take(R * c.num_actions); a->w_dvalue = take(R);
-  a->w_g[0] = take(R * mw); a->w_g[1] = take(R * mw);
+  for (int k = 0; k < 2; ++k) for (int l = 0; l < PPO_MAX_LAYERS; ++l) a->w_g[k][l] = take(R * mw);
   size_t thin_blocks = (R + 31) / 32;
-  a->w_slabs = take(std::max<size_t>((size_t)a->splits * (maxw + mw), thin_blocks * (16 * 1024 + 16)));
+  for (int k = 0; k < 2; ++k) a->w_slabs[k] = take(std::max<size_t>((size_t)a->splits * (maxw + mw), thin_blocks * (16 * 1024 + 16)));
   a->w_partial = take((size_t)RED_BLOCKS * 24);
   a->w_lastval = take(c.num_envs);
   a->w_total = w;
@@ -459,27 +465,43 @@ static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const si
 }
 
 // backward through one MLP given dHead[M, out_last]; writes weight/bias gradients into d_grads
-static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, const float* dHead, hipStream_t s) {
+static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, const float* dHead, hipStream_t s, int set) {
   float* ws = a->b.d_workspace; const float* P = a->b.d_params; float* G = a->b.d_grads;
-  float* slabs = ws + a->w_slabs;
+  float* slabs = ws + a->w_slabs[set];
   const int last = n.nl - 1;
-  // thin head: dZ_{last-1}, dW_last, db_last
-  float* gcur = ws + a->w_g[0];
-  float* gnext = ws + a->w_g[1];
+  // Weight gradients are off the critical path: they run on this network's side stream, ordered after the kernel that
+  // produced their input gradient (event per layer) and reusing one slab buffer in stream order; every layer has its own
+  // gradient buffer g[i] = dL/dz_i so the data-gradient chain never overwrites what a weight-gradient GEMM still reads.
+  // Measured on MI355X (pointfoot_rough, B = 24 576): actor||critic concurrency takes the update from 23.1 to 20.1 ms; putting
+  // the weight-gradient GEMMs on side streams as well adds nothing (20.5 ms), so it is off unless PF_PPO_SIDE_STREAMS=1.
+  hipStream_t sd = (a->dual && a->use_side && a->side[set]) ? a->side[set] : s;
+  auto g_of = [&](int i) { return ws + a->w_g[set][i]; };
+  auto side_after = [&](int i) { if (sd != s) { (void)hipEventRecord(a->ev_side[set][i], s); (void)hipStreamWaitEvent(sd, a->ev_side[set][i], 0); } };
+  // thin head: g[last-1] = dZ_{last-1}, dW_last, db_last (one kernel; its slab reduce goes to the side stream)
   {
     const Layer& L = n.l[last];
     int rows_per_block = 32, nblk = (M + rows_per_block - 1) / rows_per_block;
     int threads = (L.in + 63) / 64 * 64;
+    float* hslabs = slabs + (size_t)a->splits * 0;      // head slabs share the buffer: the side stream runs in order
     hipLaunchKernelGGL((k_thin_bwd<16>), dim3(nblk), dim3(threads), 0, s, M, L.in, L.out, rows_per_block, dHead, ws + w_h[last - 1], P + L.w,
-                       gcur, slabs);
+                       g_of(last - 1), hslabs);
+    side_after(last);
     int nw = L.out * L.in + L.out;       // W then b, contiguous in the flat gradient buffer
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, s, nw, nblk, slabs, G + L.w);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, sd, nw, nblk, hslabs, G + L.w);
   }
   for (int i = last - 1; i >= 0; --i) {
     const Layer& L = n.l[i];
     const float* in = i == 0 ? X : ws + w_h[i - 1];
+    const float* gcur = g_of(i);
+    if (i > 0) {
+      // dZ_{i-1} = (gcur[M,out] * W_i[out,in]) * ELU'(h_{i-1})      -- critical path, main stream
+      GemmArgs g{};
+      g.A = gcur; g.B = P + L.w; g.C = g_of(i - 1); g.M = M; g.N = L.in; g.K = L.out; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
+      g.H = ws + w_h[i - 1]; g.ldh = L.in;
+      pf_gemm_auto<true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
+    }
     // dW_i = gcur[M, out]^T * in[M, in] and db_i = column sums of gcur, both as split-K slabs [S][out*in + out]
-    // (rows split across blockIdx.z; deterministic slab reduce straight into the flat gradient: W then b)
+    // (rows split across blockIdx.z; deterministic slab reduce straight into the flat gradient: W then b)  -- side stream
     {
       GemmArgs g{};
       g.A = gcur; g.B = in; g.C = slabs; g.M = L.out; g.N = L.in; g.K = M; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
@@ -488,21 +510,29 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
       int per = ((M + want - 1) / want + 31) / 32 * 32;
       int S = (M + per - 1) / per;
       g.k_per_split = per;
-      if (tile == 0) pf_gemm_launch<128, 128, false, false, GEMM_EPI_NONE, true>(g, S, s);
-      else if (tile == 1) pf_gemm_launch<128, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
-      else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
+      if (tile == 0) pf_gemm_launch<128, 128, false, false, GEMM_EPI_NONE, true>(g, S, sd);
+      else if (tile == 1) pf_gemm_launch<128, 64, false, false, GEMM_EPI_NONE, true>(g, S, sd);
+      else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE, true>(g, S, sd);
       int nw = L.out * L.in + L.out;
-      hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, s, nw, S, slabs, G + L.w);
+      hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, sd, nw, S, slabs, G + L.w);
     }
-    if (i > 0) {
-      // dZ_{i-1} = (gcur[M,out] * W_i[out,in]) * ELU'(h_{i-1})
-      GemmArgs g{};
-      g.A = gcur; g.B = P + L.w; g.C = gnext; g.M = M; g.N = L.in; g.K = L.out; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
-      g.H = ws + w_h[i - 1]; g.ldh = L.in;
-      pf_gemm_auto<true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
-      std::swap(gcur, gnext);
-    }
+    if (i > 0) side_after(i);     // the next layer's weight gradient needs g[i-1], produced by the GEMM just queued on s
   }
+  if (sd != s) { (void)hipEventRecord(a->ev_side_done[set], sd); (void)hipStreamWaitEvent(s, a->ev_side_done[set], 0); }
+}
+
+// The actor and the critic are independent networks: run the critic on a second stream so one network's launch tails,
+// prologues and epilogues overlap the other's main loops (both are matrix-pipe bound; the gain is in the gaps).
+static hipStream_t ppo_fork(PpoAlg* a, hipStream_t s) {
+  if (!a->dual || !a->aux) return s;
+  (void)hipEventRecord(a->ev_fork, s);
+  (void)hipStreamWaitEvent(a->aux, a->ev_fork, 0);
+  return a->aux;
+}
+static void ppo_join(PpoAlg* a, hipStream_t s, hipStream_t other) {
+  if (other == s) return;
+  (void)hipEventRecord(a->ev_join, other);
+  (void)hipStreamWaitEvent(s, a->ev_join, 0);
 }
 
 extern "C" {
@@ -556,9 +586,38 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
   PpoAlg* a = new PpoAlg();
   a->cfg = *cfg; a->device = device;
   ppo_plan(a);
+  const char* e = getenv("PF_PPO_DUAL_STREAM");
+  a->dual = e ? atoi(e) != 0 : true;
+  const char* e2 = getenv("PF_PPO_SIDE_STREAMS");
+  a->use_side = e2 ? atoi(e2) != 0 : false;
+  if (a->dual) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming) != hipSuccess) {
+      a->aux = nullptr; a->dual = false;     // no GPU visible (host-only use of ppo_num_params etc.): single stream
+      (void)hipGetLastError();
+    } else {
+      for (int k = 0; k < 2; ++k) {
+        (void)hipStreamCreateWithFlags(&a->side[k], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&a->ev_side_done[k], hipEventDisableTiming);
+        for (int l = 0; l <= PPO_MAX_LAYERS; ++l) (void)hipEventCreateWithFlags(&a->ev_side[k][l], hipEventDisableTiming);
+      }
+    }
+  }
   return a;
 }
-void ppo_destroy(PpoAlg* a) { delete a; }
+void ppo_destroy(PpoAlg* a) {
+  if (!a) return;
+  if (a->aux) (void)hipStreamDestroy(a->aux);
+  if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
+  if (a->ev_join) (void)hipEventDestroy(a->ev_join);
+  for (int k = 0; k < 2; ++k) {
+    if (a->side[k]) (void)hipStreamDestroy(a->side[k]);
+    if (a->ev_side_done[k]) (void)hipEventDestroy(a->ev_side_done[k]);
+    for (int l = 0; l <= PPO_MAX_LAYERS; ++l) if (a->ev_side[k][l]) (void)hipEventDestroy(a->ev_side[k][l]);
+  }
+  delete a;
+}
 
 int ppo_bind_buffers(PpoAlg* a, const PpoBuffers* b) {
   if (!a || !b) { pf_set_error("ppo_bind_buffers: null argument"); return 1; }
@@ -578,8 +637,10 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   hipStream_t s = (hipStream_t)stream;
   const int N = c.num_envs, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   float* ws = a->b.d_workspace;
+  hipStream_t s2 = ppo_fork(a, s);
   mlp_forward(a, a->actor, d_obs, N, a->w_ha, s);
-  mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s);
+  mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s2);
+  ppo_join(a, s, s2);
   size_t tn = (size_t)t * N;
   hipLaunchKernelGGL(k_sample, dim3(std::max((N + 255) / 256, 512)), dim3(256), 0, s, N, A, O, P, d_obs, d_critic_obs, ws + a->w_ha[a->actor.nl - 1],
                      ws + a->w_hc[a->critic.nl - 1], a->b.d_params + a->std_off, d_inject_normal, c.seed_lo, c.seed_hi, (uint32_t)sample_counter,
@@ -654,16 +715,20 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
     ga.njobs = 9;
     hipLaunchKernelGGL(k_gather, dim3(240, 9), dim3(256), 0, s, B, perm, ga);
   }
+  hipStream_t s2 = ppo_fork(a, s);
   mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s);
-  mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s);
+  mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s2);
+  ppo_join(a, s, s2);
   const float* stdp = a->b.d_params + a->std_off;
   hipLaunchKernelGGL(k_loss, dim3(RED_BLOCKS), dim3(256), 0, s, B, A, c.clip_param, c.value_loss_coef, c.entropy_coef, c.use_clipped_value_loss,
                      ws + a->w_ha[a->actor.nl - 1], ws + a->w_hc[a->critic.nl - 1], stdp, ws + a->w_act, ws + a->w_oldlogp, ws + a->w_oldmu,
                      ws + a->w_oldsig, ws + a->w_adv, ws + a->w_ret, ws + a->w_oldval, ws + a->w_dmean, ws + a->w_dvalue, ws + a->w_partial);
   hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, RED_BLOCKS, A, B, c.entropy_coef, ws + a->w_partial, stdp,
                      a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
-  mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, ws + a->w_dmean, s);
-  mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, ws + a->w_dvalue, s);
+  s2 = ppo_fork(a, s);
+  mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, ws + a->w_dmean, s, 0);
+  mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, ws + a->w_dvalue, s2, 1);
+  ppo_join(a, s, s2);
   PPO_HIP_OK(hipGetLastError());
   return 0;
 }
