@@ -167,13 +167,19 @@ __global__ void k_reduce_slabs(int n, int S, const float* __restrict__ slabs, fl
   __shared__ float sm[4][64];
   int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
   int i = blockIdx.x * 64 + col;
-  float a0 = 0.0f, a1 = 0.0f;
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.0f;
   if (i < n) {
+    // eight independent loads in flight per thread: the narrow layers have few columns and many slabs
     int k = sl;
-    for (; k + 4 < S; k += 8) { a0 += slabs[(size_t)k * n + i]; a1 += slabs[(size_t)(k + 4) * n + i]; }
-    for (; k < S; k += 4) a0 += slabs[(size_t)k * n + i];
+    for (; k + 28 < S; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += slabs[(size_t)(k + 4 * u) * n + i];
+    }
+    for (; k < S; k += 4) a[0] += slabs[(size_t)k * n + i];
   }
-  sm[sl][col] = a0 + a1;
+  sm[sl][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   if (sl == 0 && i < n) out[i] = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
 }
@@ -199,17 +205,29 @@ __global__ void k_thin_fwd(int M, int K, int NO, const float* __restrict__ X, co
   extern __shared__ float sw[];   // NO*K
   for (int i = threadIdx.x; i < NO * K; i += blockDim.x) sw[i] = W[i];
   __syncthreads();
-  // 8 lanes cooperate on one row so the row read is one contiguous burst
+  // 8 lanes cooperate on one row so the row read is one contiguous burst (16 B per lane when K % 4 == 0)
   int lane8 = threadIdx.x & 7;
   int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   if (row >= M) return;
   float acc[NO_MAX];
 #pragma unroll
   for (int o = 0; o < NO_MAX; ++o) acc[o] = 0.0f;
-  for (int k = lane8; k < K; k += 8) {
-    float x = X[(size_t)row * K + k];
+  if ((K & 3) == 0) {
+    const float4* xr = reinterpret_cast<const float4*>(X + (size_t)row * K);
+    for (int k4 = lane8; k4 < (K >> 2); k4 += 8) {
+      float4 x = xr[k4];
 #pragma unroll
-    for (int o = 0; o < NO_MAX; ++o) if (o < NO) acc[o] += x * sw[o * K + k];
+      for (int o = 0; o < NO_MAX; ++o) if (o < NO) {
+        float4 w = *reinterpret_cast<const float4*>(&sw[o * K + 4 * k4]);
+        acc[o] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+      }
+    }
+  } else {
+    for (int k = lane8; k < K; k += 8) {
+      float x = X[(size_t)row * K + k];
+#pragma unroll
+      for (int o = 0; o < NO_MAX; ++o) if (o < NO) acc[o] += x * sw[o * K + k];
+    }
   }
 #pragma unroll
   for (int o = 0; o < NO_MAX; ++o) {
@@ -229,7 +247,20 @@ __global__ void k_thin_bwd(int M, int K, int NO, int rows_per_block, const float
   float w[NO_MAX], dw[NO_MAX], db[NO_MAX];
 #pragma unroll
   for (int o = 0; o < NO_MAX; ++o) { w[o] = (o < NO && k < K) ? W[o * K + k] : 0.0f; dw[o] = 0.0f; db[o] = 0.0f; }
-  for (int r = r0; r < r1; ++r) {
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {       // four rows in flight per thread
+    float h[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { h[u] = k < K ? H[(size_t)(r + u) * K + k] : 0.0f; g[u] = 0.0f; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int o = 0; o < NO_MAX; ++o) if (o < NO) { float d = dY[(size_t)(r + u) * NO + o]; g[u] += d * w[o]; dw[o] += d * h[u]; db[o] += d; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (k < K) Gprev[(size_t)(r + u) * K + k] = g[u] * (h[u] > 0.0f ? 1.0f : h[u] + 1.0f);
+  }
+  for (; r < r1; ++r) {
     float h = k < K ? H[(size_t)r * K + k] : 0.0f, g = 0.0f;
 #pragma unroll
     for (int o = 0; o < NO_MAX; ++o) if (o < NO) { float d = dY[(size_t)r * NO + o]; g += d * w[o]; dw[o] += d * h; db[o] += d; }
