@@ -240,6 +240,9 @@ void pf_destroy(PfEnv* env);
 int pf_bind_buffers(PfEnv* env, const PfBuffers* bufs);
 /* re-point d_reset_stats (host-only; lets the caller rotate per-step statistics slots without copies) */
 int pf_set_reset_stats(PfEnv* env, float* d_reset_stats);
+/* optional: announce the slot the FOLLOWING step will use; the step kernel clears it on the device, so a rollout that
+ * rotates slots issues no memset between steps (a slot not announced this way is cleared by pf_step itself) */
+int pf_set_reset_stats_next(PfEnv* env, float* d_next_reset_stats);
 /* replaces: gymapi tensors + update hooks; re-uploads config (e.g. after update_cmd / cfg edits) */
 int pf_update_config(PfEnv* env, const PfConfig* cfg);
 

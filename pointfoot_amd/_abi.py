@@ -161,6 +161,8 @@ def load():
     lib.pf_update_config.argtypes = [vp, C.POINTER(PfConfig)]
     lib.pf_set_reset_stats.argtypes = [vp, vp]
     lib.pf_set_reset_stats.restype = i32
+    lib.pf_set_reset_stats_next.argtypes = [vp, vp]
+    lib.pf_set_reset_stats_next.restype = i32
     lib.pf_step.argtypes = [vp, vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_reset_all.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_compute_observations.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
@@ -199,7 +201,7 @@ def check(rc, lib=None):
 
 
 EXPORTED_SYMBOLS = [
-    "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers", "pf_set_reset_stats",
+    "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers", "pf_set_reset_stats", "pf_set_reset_stats_next",
     "pf_update_config", "pf_step", "pf_reset_all", "pf_compute_observations",
     "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_workspace_floats", "ppo_act",
     "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",

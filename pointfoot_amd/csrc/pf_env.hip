@@ -32,6 +32,8 @@ __global__ __launch_bounds__(64, WAVES) void pf_step_kernel(const PfModel* __res
   using K = PfKernel<NB, ND, NF, KIND, KS>;
   __shared__ typename K::Shared sh;
   g.model = model; g.cfg = cfg;
+  // the slot the *next* launch accumulates into is cleared here, so a rollout needs no memset between steps
+  if (blockIdx.x == 0 && g.stats_next && threadIdx.x < PF_STATS_FLOATS) g.stats_next[threadIdx.x] = 0.0f;
   K::run(sh, g, (int)blockIdx.x);
 }
 
@@ -46,6 +48,8 @@ struct PfEnv {
   bool bound = false;
   int instance = 0;
   unsigned* d_stamps = nullptr;   // diagnostic build (-DPF_STAMPS) only
+  float* stats_next = nullptr;    // pf_set_reset_stats_next: slot the following step will use
+  float* stats_cleared = nullptr; // slot already cleared on the device by the previous launch
 };
 
 extern "C" {
@@ -143,6 +147,12 @@ int pf_set_reset_stats(PfEnv* e, float* d_reset_stats) {
   return 0;
 }
 
+int pf_set_reset_stats_next(PfEnv* e, float* d_next) {
+  if (!e || !e->bound) { pf_set_error("pf_set_reset_stats_next: buffers not bound"); return 1; }
+  e->stats_next = d_next;
+  return 0;
+}
+
 /* diagnostic build only: per-env phase cycle counters (PF_NSTAMP unsigned per env); not part of the boundary */
 int pf_debug_set_stamps(PfEnv* e, unsigned* d_stamps) { if (!e) return 1; e->d_stamps = d_stamps; return 0; }
 
@@ -169,7 +179,13 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   }
   g.actions = d_actions; g.step_counter = step_counter; g.mode = mode; g.stamps = e->d_stamps;
   hipStream_t s = (hipStream_t)stream;
-  if (e->bufs.d_reset_stats && mode != 2) PF_HIP_OK(hipMemsetAsync(e->bufs.d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS, s));
+  g.stats_next = nullptr;
+  if (e->bufs.d_reset_stats && mode != 2) {
+    // cleared by the previous launch when the caller announced it with pf_set_reset_stats_next; otherwise clear it now
+    if (e->stats_cleared != e->bufs.d_reset_stats) PF_HIP_OK(hipMemsetAsync(e->bufs.d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS, s));
+    g.stats_next = (e->stats_next && e->stats_next != e->bufs.d_reset_stats) ? e->stats_next : nullptr;
+    e->stats_cleared = g.stats_next;
+  }
   // PF_STEP_WAVES selects the register budget variant (waves per SIMD the kernel is compiled for)
   static const int variant = [] { const char* v = getenv("PF_STEP_WAVES"); return v ? atoi(v) : 4; }();
   dim3 grid(e->cfg.num_envs), block(64);

@@ -190,10 +190,11 @@ struct GatherArgs { GatherJob job[9]; int njobs; };
 // rsl_rl mini_batch_generator: rows perm[b] of every storage array -> contiguous minibatch arrays (one launch)
 __global__ void k_gather(int B, const int* __restrict__ perm, GatherArgs ga) {
   const GatherJob j = ga.job[blockIdx.y];
-  size_t n = (size_t)B * j.cols;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    int r = (int)(i / j.cols), c = (int)(i - (size_t)r * j.cols);
-    j.dst[i] = j.src[(size_t)perm[r] * j.cols + c];
+  // 32-bit index arithmetic (the host checks B * cols < 2^31): a 64-bit divide per element made this kernel ALU-bound
+  const unsigned cols = (unsigned)j.cols, n = (unsigned)B * cols, stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    unsigned r = i / cols, c = i - r * cols;
+    j.dst[i] = j.src[(size_t)perm[r] * cols + c];
   }
 }
 
@@ -440,6 +441,11 @@ static int ppo_check_cfg(const PpoConfig* c) {
   if (c->actor_dims[0] != c->num_obs || c->critic_dims[0] != c->num_critic_obs || c->actor_dims[c->n_actor_layers] != c->num_actions ||
       c->critic_dims[c->n_critic_layers] != 1) { pf_set_error("ppo: layer dims inconsistent with obs/action sizes"); return 1; }
   if ((c->num_envs * c->num_steps) % c->num_mini_batches != 0) { pf_set_error("ppo: num_envs*num_steps must divide by num_mini_batches"); return 1; }
+  {
+    long long rows = (long long)c->num_envs * c->num_steps / c->num_mini_batches;
+    long long widest = c->num_obs > c->num_critic_obs ? c->num_obs : c->num_critic_obs;
+    if (rows * widest >= (1ll << 31)) { pf_set_error("ppo: minibatch rows * obs width must stay below 2^31"); return 1; }
+  }
   for (int i = 1; i < c->n_actor_layers; ++i) if (c->actor_dims[i] > 1024) { pf_set_error("ppo: hidden width > 1024"); return 1; }
   for (int i = 1; i < c->n_critic_layers; ++i) if (c->critic_dims[i] > 1024) { pf_set_error("ppo: hidden width > 1024"); return 1; }
   return 0;

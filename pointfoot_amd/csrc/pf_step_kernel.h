@@ -125,6 +125,7 @@ struct PfStepArgs {
   long long step_counter;
   int mode;               // 0 = step, 1 = reset_idx(all), 2 = compute_observations only
   unsigned* stamps;       // diagnostic build only, else NULL
+  float* stats_next;      // next step's statistics slot, cleared by this launch (NULL: the host clears slots itself)
 };
 
 template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH>

@@ -192,6 +192,8 @@ class HipEnv:
         self._stats_slot = (self._stats_slot + 1) % self._stats_ring.shape[0]
         self._reset_stats = self._stats_ring[self._stats_slot]
         _abi.check(self._lib.pf_set_reset_stats(self._h, self._reset_stats.data_ptr()), self._lib)
+        nxt = self._stats_ring[(self._stats_slot + 1) % self._stats_ring.shape[0]]
+        _abi.check(self._lib.pf_set_reset_stats_next(self._h, nxt.data_ptr()), self._lib)
 
     def _fill_extras(self):
         # reference :276-288

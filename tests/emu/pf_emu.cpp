@@ -10,7 +10,7 @@ extern "C" int pfe_step(const PfModel* model, const PfConfig* cfg, const PfLayou
   PfStepArgs g;
   g.model = model; g.cfg = cfg; g.L = *layout; g.b = *bufs;
   if (inject) g.inj = *inject; else std::memset(&g.inj, 0, sizeof(g.inj));
-  g.actions = actions; g.step_counter = step_counter; g.mode = mode; g.stamps = nullptr;
+  g.actions = actions; g.step_counter = step_counter; g.mode = mode; g.stamps = nullptr; g.stats_next = nullptr;
   if (bufs->d_reset_stats && mode != 2) std::memset(bufs->d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS);
   if (cfg->env_kind == PF_KIND_POINTFOOT && model->nb == 9 && model->nd == 6 && model->nfeet == 2) {
     using K = PfKernel<9, 6, 2, PF_KIND_POINTFOOT>;
