@@ -17,7 +17,6 @@
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { GEMM_EPI_NONE = 0, GEMM_EPI_BIAS = 1, GEMM_EPI_BIAS_ELU = 2, GEMM_EPI_MUL_DELU = 3 };
 
@@ -28,13 +27,20 @@ struct GemmArgs {
   const float* bias;    // [N]            (EPI_BIAS*)
   const float* H;       // [M, ldh]       (EPI_MUL_DELU: C *= (H > 0 ? 1 : H + 1))
   int ldh;
-  int k_per_split;      // BWD_W: rows of the reduction handled per blockIdx.z (multiple of 32); C slab z at C + z*M*ldc
+  int k_per_split;      // BWD_W: rows of the reduction handled per split (multiple of 32); C slab z at C + z*M*ldc
+  int nsplit;           // number of splits (set by pf_gemm_launch)
 };
 
 __device__ __forceinline__ float pf_elu(float x) { return x > 0.0f ? x : (__expf(x) - 1.0f); }
 
 // A_KC: A stored [M][K] (k contiguous) else [K][M] (m contiguous).  B_KC: B stored [N][K] else [K][N].
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false, bool MF16 = false>
+//
+// The grid is one-dimensional and *persistent-capable*: block b walks tiles b, b + gridDim.x, ... of the
+// (M tiles) x (N tiles) x (splits) space.  Before a block writes a finished tile it has already issued the global loads
+// of its next tile's first k-slice, so the C-tile write (with bias/ELU) and the next tile's load latency overlap instead
+// of adding up.  Tile numbers are remapped so the eight XCDs (round-robin over workgroup ids, one L2 each) each own a
+// contiguous range of tiles: blocks that share A rows / B columns hit the same L2.
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
 __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
   constexpr int BK = 32;
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -43,14 +49,26 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  int k_begin = 0, k_end = g.K;
-  float* Cout = g.C;
-  if (g.k_per_split > 0) {
-    k_begin = blockIdx.z * g.k_per_split;
-    k_end = min(g.K, k_begin + g.k_per_split);
-    Cout += (size_t)blockIdx.z * ((size_t)g.M * g.ldc + (COLSUM ? g.M : 0));
-  }
+  const int tiles_x = (g.N + BN - 1) / BN, tiles_y = (g.M + BM - 1) / BM;
+  const int nsplit = g.nsplit > 0 ? g.nsplit : 1;
+  const int ntiles = tiles_x * tiles_y * nsplit;
+  const int per_xcd = (ntiles + 7) >> 3, tmax = per_xcd << 3;
+
+  struct Tile { int m0, n0, k_begin, k_end, bx; float* C; };
+  auto decode = [&](int t, Tile& T) -> bool {
+    int lt = (t & 7) * per_xcd + (t >> 3);      // XCD (t & 7) owns logical tiles [xcd * per_xcd, (xcd + 1) * per_xcd)
+    if (lt >= ntiles) return false;
+    int bx = lt % tiles_x, rest = lt / tiles_x;
+    int by = rest % tiles_y, bz = rest / tiles_y;
+    T.bx = bx; T.m0 = by * BM; T.n0 = bx * BN; T.k_begin = 0; T.k_end = g.K; T.C = g.C;
+    if (g.k_per_split > 0) {
+      T.k_begin = bz * g.k_per_split;
+      T.k_end = min(g.K, T.k_begin + g.k_per_split);
+      T.C += (size_t)bz * ((size_t)g.M * g.ldc + (COLSUM ? g.M : 0));
+    }
+    return true;
+  };
+
   constexpr int A_V4 = BM * BK / 4 / 256, B_V4 = BN * BK / 4 / 256;   // float4 chunks per thread
   float4 ra[A_V4], rb[B_V4];
 
@@ -69,18 +87,18 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
     }
     return v;
   };
-  auto fetch = [&](int k0) {
+  auto fetch = [&](const Tile& T, int k0) {
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) {
       int idx = tid + 256 * i;
-      if (A_KC) { int r = idx / (BK / 4), c4 = idx % (BK / 4); ra[i] = load4(g.A, g.lda, m0 + r, k0 + c4 * 4, g.M, k_end); }
-      else { int r = idx / (BM / 4), c4 = idx % (BM / 4); ra[i] = load4(g.A, g.lda, k0 + r, m0 + c4 * 4, k_end, g.M); }
+      if (A_KC) { int r = idx / (BK / 4), c4 = idx % (BK / 4); ra[i] = load4(g.A, g.lda, T.m0 + r, k0 + c4 * 4, g.M, T.k_end); }
+      else { int r = idx / (BM / 4), c4 = idx % (BM / 4); ra[i] = load4(g.A, g.lda, k0 + r, T.m0 + c4 * 4, T.k_end, g.M); }
     }
 #pragma unroll
     for (int i = 0; i < B_V4; ++i) {
       int idx = tid + 256 * i;
-      if (B_KC) { int r = idx / (BK / 4), c4 = idx % (BK / 4); rb[i] = load4(g.B, g.ldb, n0 + r, k0 + c4 * 4, g.N, k_end); }
-      else { int r = idx / (BN / 4), c4 = idx % (BN / 4); rb[i] = load4(g.B, g.ldb, k0 + r, n0 + c4 * 4, k_end, g.N); }
+      if (B_KC) { int r = idx / (BK / 4), c4 = idx % (BK / 4); rb[i] = load4(g.B, g.ldb, T.n0 + r, k0 + c4 * 4, g.N, T.k_end); }
+      else { int r = idx / (BN / 4), c4 = idx % (BN / 4); rb[i] = load4(g.B, g.ldb, k0 + r, T.n0 + c4 * 4, T.k_end, g.N); }
     }
   };
   auto stage = [&]() {
@@ -110,15 +128,14 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
     }
   };
 
-  float csum = 0.0f;   // COLSUM: sum over the reduction rows of A[:, m0 + tid] (bias gradient), blocks with blockIdx.x == 0
-  auto epilogue_store = [&](int row, int col, float v) {
-    if (row >= g.M || col >= g.N) return;
-    if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) v += g.bias[col];
-    if (EPI == GEMM_EPI_BIAS_ELU) v = pf_elu(v);
-    if (EPI == GEMM_EPI_MUL_DELU) { float h = g.H[(size_t)row * g.ldh + col]; v *= (h > 0.0f ? 1.0f : h + 1.0f); }
-    Cout[(size_t)row * g.ldc + col] = v;
-  };
-  if constexpr (!MF16) {
+  Tile cur;
+  int t = blockIdx.x;
+  while (t < tmax && !decode(t, cur)) t += gridDim.x;
+  if (t >= tmax) return;
+  fetch(cur, cur.k_begin);
+  const int arow = wr * (BM / 2) + (lane & 31), bcol = wc * (BN / 2) + (lane & 31), kh = lane >> 5;
+
+  while (true) {
     // ---- v_mfma_f32_32x32x2_f32: wave tile = TM x TN tiles of 32x32
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -127,14 +144,13 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const int arow = wr * (BM / 2) + (lane & 31), bcol = wc * (BN / 2) + (lane & 31), kh = lane >> 5;
-    fetch(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-      __syncthreads();          // previous tile fully consumed
+    float csum = 0.0f;   // COLSUM: sum over the reduction rows of A[:, m0 + tid] (bias gradient), tiles with bx == 0
+    for (int k0 = cur.k_begin; k0 < cur.k_end; k0 += BK) {
+      __syncthreads();          // previous k-slice (or previous tile) fully consumed
       stage();
       __syncthreads();
-      if (k0 + BK < k_end) fetch(k0 + BK);
-      if (COLSUM && blockIdx.x == 0 && tid < BM) {
+      if (k0 + BK < cur.k_end) fetch(cur, k0 + BK);
+      if (COLSUM && cur.bx == 0 && tid < BM) {
 #pragma unroll
         for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDA_S + tid];
       }
@@ -151,69 +167,49 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (COLSUM && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) Cout[(size_t)g.M * g.ldc + m0 + tid] = csum;
+    // next tile of this block: get its first k-slice in flight before the write-out below
+    Tile nxt;
+    int tn = t + gridDim.x;
+    bool more = false;
+    while (tn < tmax) { if (decode(tn, nxt)) { more = true; break; } tn += gridDim.x; }
+    if (more) fetch(nxt, nxt.k_begin);
+
+    if (COLSUM && cur.bx == 0 && tid < BM && cur.m0 + tid < g.M) cur.C[(size_t)g.M * g.ldc + cur.m0 + tid] = csum;
     // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        int col = n0 + wc * (BN / 2) + 32 * j + (lane & 31);
+        const int col = cur.n0 + wc * (BN / 2) + 32 * j + (lane & 31);
+        float bias = 0.0f;
+        if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) bias = col < g.N ? g.bias[col] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) epilogue_store(m0 + wr * (BM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col, acc[i][j][r]);
+        for (int r = 0; r < 16; ++r) {
+          const int row = cur.m0 + wr * (BM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row >= g.M || col >= g.N) continue;
+          float v = acc[i][j][r];
+          if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) v += bias;
+          if (EPI == GEMM_EPI_BIAS_ELU) v = pf_elu(v);
+          if (EPI == GEMM_EPI_MUL_DELU) { float h = g.H[(size_t)row * g.ldh + col]; v *= (h > 0.0f ? 1.0f : h + 1.0f); }
+          cur.C[(size_t)row * g.ldc + col] = v;
+        }
       }
-  } else {
-    // ---- v_mfma_f32_16x16x4_f32: wave tile = (2 TM) x (2 TN) tiles of 16x16; A[l&15][k=l>>4], B[k=l>>4][l&15]
-    constexpr int UM = 2 * TM, UN = 2 * TN;
-    f32x4 acc[UM][UN];
-#pragma unroll
-    for (int i = 0; i < UM; ++i)
-#pragma unroll
-      for (int j = 0; j < UN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
-    const int arow = wr * (BM / 2) + (lane & 15), bcol = wc * (BN / 2) + (lane & 15), kq = lane >> 4;
-    fetch(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-      __syncthreads();
-      stage();
-      __syncthreads();
-      if (k0 + BK < k_end) fetch(k0 + BK);
-      if (COLSUM && blockIdx.x == 0 && tid < BM) {
-#pragma unroll
-        for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDA_S + tid];
-      }
-#pragma unroll
-      for (int kk = 0; kk < BK / 4; ++kk) {
-        float a[UM], b[UN];
-#pragma unroll
-        for (int i = 0; i < UM; ++i) a[i] = As[(4 * kk + kq) * LDA_S + arow + 16 * i];
-#pragma unroll
-        for (int j = 0; j < UN; ++j) b[j] = Bs[(4 * kk + kq) * LDB_S + bcol + 16 * j];
-#pragma unroll
-        for (int i = 0; i < UM; ++i)
-#pragma unroll
-          for (int j = 0; j < UN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    if (COLSUM && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) Cout[(size_t)g.M * g.ldc + m0 + tid] = csum;
-    // C/D layout: col = lane&15, row = (lane>>4)*4 + r
-#pragma unroll
-    for (int i = 0; i < UM; ++i)
-#pragma unroll
-      for (int j = 0; j < UN; ++j) {
-        int col = n0 + wc * (BN / 2) + 16 * j + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) epilogue_store(m0 + wr * (BM / 2) + 16 * i + (lane >> 4) * 4 + r, col, acc[i][j][r]);
-      }
+    if (!more) break;
+    cur = nxt; t = tn;
   }
 }
 
-static inline bool pf_gemm_use_mf16() { static const bool v = [] { const char* e = getenv("PF_GEMM_MF16"); return e ? atoi(e) != 0 : false; }(); return v; }
+// PF_GEMM_PERSIST = resident blocks per CU for the persistent grid (0: one block per tile)
+static inline int pf_gemm_persist() { static const int v = [] { const char* e = getenv("PF_GEMM_PERSIST"); return e ? atoi(e) : 0; }(); return v; }
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
-static inline void pf_gemm_launch(const GemmArgs& g, int splits, hipStream_t s) {
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits > 0 ? splits : 1);
-  if (pf_gemm_use_mf16()) hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, false>), grid, dim3(256), 0, s, g);
+static inline void pf_gemm_launch(const GemmArgs& g_in, int splits, hipStream_t s) {
+  GemmArgs g = g_in;
+  g.nsplit = splits > 0 ? splits : 1;
+  int ntiles = ((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM) * g.nsplit;
+  int blocks = (ntiles + 7) / 8 * 8;
+  int p = pf_gemm_persist();
+  if (p > 0 && blocks > p * 256) blocks = p * 256;
+  hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM>), dim3(blocks), dim3(256), 0, s, g);
 }
 
 // Tile choice from a small cost model calibrated on MI355X (tools/gemm_bench.py): the main loop runs at the matrix
