@@ -7,10 +7,14 @@
 //     BWD_W: C = G[Kr,M]^T * X[Kr,N]     A m-contiguous, B n-contiguous, reduction over rows Kr split across
 //                                         blockIdx.z into slabs (deterministic two-stage reduce, no atomics)
 // Tiling: 256 threads = 4 wavefronts (2x2); block tile BM x BN with BM,BN in {64,128}, BK = 32; each wave owns
-// (BM/2)x(BN/2) = TMxTN tiles of 32x32.  Both operands are staged in LDS k-major (As[k][m], Bs[k][n]) so a
-// fragment read is 32 consecutive floats per half-wave (conflict-free ds_read_b32); row stride +1/+4 padded so the
-// transposing stores of k-contiguous operands are conflict-free too.  The next k-tile is prefetched into
-// registers while the current one feeds the MFMAs.
+// (BM/2)x(BN/2) = TMxTN tiles of 32x32.  Both operands are staged in LDS row-major over the tile's m (or n) index with the
+// 32 k values of a slice permuted so that the values one lane feeds to four consecutive MFMA steps are adjacent:
+// position(k) = ((k >> 1) & 1) * 16 + 2 * (k >> 2) + (k & 1)  (lane half h = lane >> 5 supplies, at MFMA step s,
+// k = 4 (s >> 1) + 2 h + (s & 1); any one-to-one assignment works as long as A and B share it).  A fragment read is then one
+// ds_read_b128 per four MFMAs per 32-row operand tile (row stride 36 floats: the 16 lanes of a b128 phase hit 64 distinct
+// banks), and a thread that holds four consecutive k of one row stores them as two ds_write_b64.  k-contiguous operands
+// are fetched as float4 along k; m-contiguous operands as four row-strided dwords (each wave load is 256 contiguous
+// bytes).  The next k-slice is prefetched into registers while the current one feeds the MFMAs.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -40,13 +44,13 @@ __device__ __forceinline__ float pf_elu(float x) { return x > 0.0f ? x : (__expf
 // of its next tile's first k-slice, so the C-tile write (with bias/ELU) and the next tile's load latency overlap instead
 // of adding up.  Tile numbers are remapped so the eight XCDs (round-robin over workgroup ids, one L2 each) each own a
 // contiguous range of tiles: blocks that share A rows / B columns hit the same L2.
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false, bool VEC = true>
 __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
   constexpr int BK = 32;
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int LDA_S = BM + (A_KC ? 1 : 4), LDB_S = BN + (B_KC ? 1 : 4);
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+  constexpr int LDS_S = BK + 4;      // row stride (floats): 16 B aligned rows, conflict-free b128 fragment reads
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_S];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_S];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_x = (g.N + BN - 1) / BN, tiles_y = (g.M + BM - 1) / BM;
@@ -72,59 +76,66 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
   constexpr int A_V4 = BM * BK / 4 / 256, B_V4 = BN * BK / 4 / 256;   // float4 chunks per thread
   float4 ra[A_V4], rb[B_V4];
 
-  auto load4 = [&](const float* base, int ld, int row, int col, int nrows, int ncols) -> float4 {
-    // 4 consecutive floats along `col`; zero outside [nrows, ncols)
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) {
-      const float* p = base + (size_t)row * ld + col;
-      if (col + 3 < ncols && ((((size_t)p) & 15) == 0)) v = *(const float4*)p;
-      else {
-        if (col < ncols) v.x = p[0];
-        if (col + 1 < ncols) v.y = p[1];
-        if (col + 2 < ncols) v.z = p[2];
-        if (col + 3 < ncols) v.w = p[3];
-      }
-    }
-    return v;
+  // Operand loads go through buffer descriptors: an out-of-range offset returns 0 in hardware, so tile edges (rows past
+  // the array, k past the end of the reduction range) need no branches and no value selects -- a lane that must read
+  // zeros just gets an out-of-range offset -- and the prefetch stays in flight across the MFMAs.  VEC: k-contiguous rows are 16 B aligned and
+  // the reduction length is a multiple of 4 (checked by pf_gemm_launch), so a row quad is one dwordx4 load.
+  constexpr unsigned OOB = 0x80000000u;                     // arrays are < 2 GiB (checked on the host)
+  const unsigned a_bytes = (unsigned)(A_KC ? g.M : g.K) * (unsigned)g.lda * 4u;
+  const unsigned b_bytes = (unsigned)(B_KC ? g.N : g.K) * (unsigned)g.ldb * 4u;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, b_bytes, 0x00020000);
+  auto ld1 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off) -> float {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
   };
+  // k-contiguous operand: 4 consecutive k of row `row`; zero outside [nrows) x [k_end)
+  auto load_kc = [&](__amdgpu_buffer_rsrc_t rs, int ld, int row, int k, int nrows, int k_end) -> float4 {
+    const unsigned off = ((unsigned)row * (unsigned)ld + (unsigned)k) * 4u;
+    const bool rv = row < nrows;
+    if constexpr (VEC)
+      return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((rv && k < k_end) ? off : OOB), 0, 0));
+    return make_float4(ld1(rs, (rv && k < k_end) ? off : OOB), ld1(rs, (rv && k + 1 < k_end) ? off + 4 : OOB),
+                       ld1(rs, (rv && k + 2 < k_end) ? off + 8 : OOB), ld1(rs, (rv && k + 3 < k_end) ? off + 12 : OOB));
+  };
+  // m-contiguous operand: rows k..k+3 of column `col` (a wave reads 64 consecutive columns per row)
+  auto load_mc = [&](__amdgpu_buffer_rsrc_t rs, int ld, int k, int col, int k_end, int ncols) -> float4 {
+    const unsigned off = ((unsigned)k * (unsigned)ld + (unsigned)col) * 4u, st = (unsigned)ld * 4u;
+    const bool cv = col < ncols;
+    return make_float4(ld1(rs, (cv && k < k_end) ? off : OOB), ld1(rs, (cv && k + 1 < k_end) ? off + st : OOB),
+                       ld1(rs, (cv && k + 2 < k_end) ? off + 2 * st : OOB), ld1(rs, (cv && k + 3 < k_end) ? off + 3 * st : OOB));
+  };
+  // thread -> (tile row, k quad): k-contiguous: 8 quads of one row are adjacent threads; m-contiguous: adjacent threads
+  // are adjacent rows
   auto fetch = [&](const Tile& T, int k0) {
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) {
       int idx = tid + 256 * i;
-      if (A_KC) { int r = idx / (BK / 4), c4 = idx % (BK / 4); ra[i] = load4(g.A, g.lda, T.m0 + r, k0 + c4 * 4, g.M, T.k_end); }
-      else { int r = idx / (BM / 4), c4 = idx % (BM / 4); ra[i] = load4(g.A, g.lda, k0 + r, T.m0 + c4 * 4, T.k_end, g.M); }
+      if (A_KC) ra[i] = load_kc(a_rs, g.lda, T.m0 + idx / (BK / 4), k0 + (idx % (BK / 4)) * 4, g.M, T.k_end);
+      else ra[i] = load_mc(a_rs, g.lda, k0 + (idx / BM) * 4, T.m0 + idx % BM, T.k_end, g.M);
     }
 #pragma unroll
     for (int i = 0; i < B_V4; ++i) {
       int idx = tid + 256 * i;
-      if (B_KC) { int r = idx / (BK / 4), c4 = idx % (BK / 4); rb[i] = load4(g.B, g.ldb, T.n0 + r, k0 + c4 * 4, g.N, T.k_end); }
-      else { int r = idx / (BN / 4), c4 = idx % (BN / 4); rb[i] = load4(g.B, g.ldb, k0 + r, T.n0 + c4 * 4, T.k_end, g.N); }
+      if (B_KC) rb[i] = load_kc(b_rs, g.ldb, T.n0 + idx / (BK / 4), k0 + (idx % (BK / 4)) * 4, g.N, T.k_end);
+      else rb[i] = load_mc(b_rs, g.ldb, k0 + (idx / BN) * 4, T.n0 + idx % BN, T.k_end, g.N);
     }
+  };
+  // v = values at k = 4q .. 4q+3 of one row: (k, k+1) feed lane half 0 at MFMA steps (2q, 2q+1), (k+2, k+3) lane half 1 at
+  // the same steps -- register pairs go to LDS as they are (one ds_write2_b64), no shuffles between load and store
+  auto put = [&](float* S, int row, int q, const float4& v) {
+    *(float2*)&S[row * LDS_S + 2 * q] = make_float2(v.x, v.y);
+    *(float2*)&S[row * LDS_S + 16 + 2 * q] = make_float2(v.z, v.w);
   };
   auto stage = [&]() {
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) {
       int idx = tid + 256 * i;
-      if (A_KC) {
-        int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
-        As[(c + 0) * LDA_S + r] = ra[i].x; As[(c + 1) * LDA_S + r] = ra[i].y;
-        As[(c + 2) * LDA_S + r] = ra[i].z; As[(c + 3) * LDA_S + r] = ra[i].w;
-      } else {
-        int r = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
-        *(float4*)&As[r * LDA_S + c] = ra[i];
-      }
+      if (A_KC) put(As, idx / (BK / 4), idx % (BK / 4), ra[i]); else put(As, idx % BM, idx / BM, ra[i]);
     }
 #pragma unroll
     for (int i = 0; i < B_V4; ++i) {
       int idx = tid + 256 * i;
-      if (B_KC) {
-        int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
-        Bs[(c + 0) * LDB_S + r] = rb[i].x; Bs[(c + 1) * LDB_S + r] = rb[i].y;
-        Bs[(c + 2) * LDB_S + r] = rb[i].z; Bs[(c + 3) * LDB_S + r] = rb[i].w;
-      } else {
-        int r = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
-        *(float4*)&Bs[r * LDB_S + c] = rb[i];
-      }
+      if (B_KC) put(Bs, idx / (BK / 4), idx % (BK / 4), rb[i]); else put(Bs, idx % BN, idx / BN, rb[i]);
     }
   };
 
@@ -152,19 +163,24 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
       if (k0 + BK < cur.k_end) fetch(cur, k0 + BK);
       if (COLSUM && cur.bx == 0 && tid < BM) {
 #pragma unroll
-        for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDA_S + tid];
+        for (int q = 0; q < BK / 4; ++q) { float4 v = *(const float4*)&As[tid * LDS_S + 4 * q]; csum += (v.x + v.y) + (v.z + v.w); }
       }
 #pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        float a[TM], b[TN];
+      for (int q = 0; q < BK / 8; ++q) {       // four MFMA steps per fragment read
+        float4 a[TM], b[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + kh) * LDA_S + arow + 32 * i];
+        for (int i = 0; i < TM; ++i) a[i] = *(const float4*)&As[(arow + 32 * i) * LDS_S + kh * 16 + 4 * q];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + kh) * LDB_S + bcol + 32 * j];
+        for (int j = 0; j < TN; ++j) b[j] = *(const float4*)&Bs[(bcol + 32 * j) * LDS_S + kh * 16 + 4 * q];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+          }
       }
     }
     // next tile of this block: get its first k-slice in flight before the write-out below
@@ -209,7 +225,13 @@ static inline void pf_gemm_launch(const GemmArgs& g_in, int splits, hipStream_t 
   int blocks = (ntiles + 7) / 8 * 8;
   int p = pf_gemm_persist();
   if (p > 0 && blocks > p * 256) blocks = p * 256;
-  hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM>), dim3(blocks), dim3(256), 0, s, g);
+  // float4 row loads of the k-contiguous operands need 16 B aligned rows and K % 4 == 0
+  bool vec = (g.K & 3) == 0;
+  if (A_KC) vec = vec && ((((size_t)g.A) & 15) == 0) && ((g.lda & 3) == 0);
+  if (B_KC) vec = vec && ((((size_t)g.B) & 15) == 0) && ((g.ldb & 3) == 0);
+  if (!A_KC && !B_KC) vec = true;      // no k-contiguous operand: one instance
+  if (vec) hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, true>), dim3(blocks), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, (A_KC || B_KC) ? false : true>), dim3(blocks), dim3(256), 0, s, g);
 }
 
 // Tile choice from a small cost model calibrated on MI355X (tools/gemm_bench.py): the main loop runs at the matrix
