@@ -313,6 +313,10 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device);
 void ppo_destroy(PpoAlg* alg);
 int ppo_bind_buffers(PpoAlg* alg, const PpoBuffers* bufs);
 int64_t ppo_num_params(const PpoConfig* cfg);
+/* Offsets (in floats) of every parameter tensor inside the flat buffer, in the order actor (W, b) per layer, critic
+ * (W, b) per layer, action std.  Tensors start on 16-byte boundaries; the padding floats between them stay zero
+ * (zero gradient, untouched by Adam).  Returns the number of tensors (writes at most max_entries), -1 on error. */
+int32_t ppo_param_offsets(const PpoConfig* cfg, int64_t* offsets, int32_t max_entries);
 int64_t ppo_workspace_floats(const PpoConfig* cfg);
 
 /* PPO.act: actor+critic forward on (obs, critic_obs), Normal(mu, std).sample(), log-prob, store

@@ -33,19 +33,34 @@ class RefActorCritic(nn.Module):
                     ps += [m.weight, m.bias]
         return ps + [self.std]
 
-    def load_flat(self, flat):
-        off = 0
+    def _spans(self, offsets):
+        """(tensor, start) in flat order; offsets=None: packed, else the starts reported by ppo_param_offsets"""
+        off, out = 0, []
+        for i, p in enumerate(self.kernel_order()):
+            if offsets is not None:
+                off = offsets[i]
+            out.append((p, off))
+            off += p.numel()
+        return out
+
+    def load_flat(self, flat, offsets=None):
         with torch.no_grad():
-            for p in self.kernel_order():
-                n = p.numel()
-                p.copy_(flat[off:off + n].view(p.shape))
-                off += n
+            for p, off in self._spans(offsets):
+                p.copy_(flat[off:off + p.numel()].view(p.shape))
 
-    def flat(self):
-        return torch.cat([p.detach().reshape(-1) for p in self.kernel_order()])
+    def _gather(self, get, offsets, total):
+        if offsets is None:
+            return torch.cat([get(p).reshape(-1) for p in self.kernel_order()])
+        out = torch.zeros(total, dtype=self.std.dtype, device=self.std.device)
+        for p, off in self._spans(offsets):
+            out[off:off + p.numel()] = get(p).reshape(-1)
+        return out
 
-    def flat_grad(self):
-        return torch.cat([p.grad.reshape(-1) for p in self.kernel_order()])
+    def flat(self, offsets=None, total=None):
+        return self._gather(lambda p: p.detach(), offsets, total)
+
+    def flat_grad(self, offsets=None, total=None):
+        return self._gather(lambda p: p.grad, offsets, total)
 
 
 def act(ac, obs, critic_obs, normal_noise):

@@ -180,6 +180,8 @@ def _bind_ppo(lib):
     lib.ppo_bind_buffers.argtypes = [vp, C.POINTER(PpoBuffers)]
     lib.ppo_num_params.argtypes = [C.POINTER(PpoConfig)]
     lib.ppo_num_params.restype = C.c_int64
+    lib.ppo_param_offsets.argtypes = [C.POINTER(PpoConfig), C.POINTER(C.c_int64), i32]
+    lib.ppo_param_offsets.restype = i32
     lib.ppo_workspace_floats.argtypes = [C.POINTER(PpoConfig)]
     lib.ppo_workspace_floats.restype = C.c_int64
     lib.ppo_act.argtypes = [vp, i32, vp, vp, vp, C.c_int64, vp, vp]
@@ -203,6 +205,6 @@ def check(rc, lib=None):
 EXPORTED_SYMBOLS = [
     "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers", "pf_set_reset_stats", "pf_set_reset_stats_next",
     "pf_update_config", "pf_step", "pf_reset_all", "pf_compute_observations",
-    "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_workspace_floats", "ppo_act",
+    "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act",
     "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",
     "ppo_minibatch_backward", "ppo_minibatch_apply"]

@@ -254,12 +254,12 @@ static inline int pf_pick_tile(int M, int N, int K, int splits) {
   return best;
 }
 // Split-K choice for the weight-gradient GEMM (output only out x in, reduction over tens of thousands of rows): measured
-// on MI355X (tools/gemm_sweep_bwdw.py) 64x64 tiles win or tie everywhere and the time is lowest when the grid is one full
-// resident round -- 6 blocks per CU x 256 CUs = 1536 blocks (512x256: 95.6 us at 1024 blocks, 88.6 at 1536, 93 at 2048;
-// 512x148: 79 / 65.8 / 71) -- so: 64x64 tiles, S = ~1536 blocks / tiles, capped by the slab workspace.
+// on MI355X (tools/gemm_sweep_bwdw.py) 64x64 tiles win or tie everywhere and the time is lowest at ~4 blocks per CU
+// (512x256: 83.8 us at 768 blocks, 78.3 at 1024, 85.7 at 1536; 512x148: 74.7 / 58.9 at 768 / 59.7 at 1152; the narrow layers
+// 26 us at 768-1024), so: 64x64 tiles, S = ~1024 blocks / tiles, capped by the slab workspace.
 static inline void pf_pick_split(int M, int N, int K, int max_splits, int* tile_out, int* splits_out) {
   int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  int S = (1536 + tiles - 1) / tiles;
+  int S = (1024 + tiles - 1) / tiles;
   if (S > max_splits) S = max_splits;
   while (S > 1 && (K + S - 1) / S < 64) --S;
   *tile_out = 2; *splits_out = S < 1 ? 1 : S;

@@ -427,8 +427,9 @@ static void net_layout(Net& n, const int* dims, int nl, size_t& off) {
   n.nl = nl;
   for (int i = 0; i < nl; ++i) {
     n.l[i].in = dims[i]; n.l[i].out = dims[i + 1];
-    n.l[i].w = off; off += (size_t)dims[i] * dims[i + 1];
-    n.l[i].b = off; off += dims[i + 1];
+    // every tensor starts on a 16-byte boundary: the GEMMs read weight rows with dwordx4 loads
+    off = (off + 3) & ~(size_t)3; n.l[i].w = off; off += (size_t)dims[i] * dims[i + 1];
+    off = (off + 3) & ~(size_t)3; n.l[i].b = off; off += dims[i + 1];
   }
 }
 
@@ -456,8 +457,9 @@ static void ppo_plan(PpoAlg* a) {
   size_t off = 0;
   net_layout(a->actor, c.actor_dims, c.n_actor_layers, off);
   net_layout(a->critic, c.critic_dims, c.n_critic_layers, off);
+  off = (off + 3) & ~(size_t)3;
   a->std_off = off; off += c.num_actions;
-  a->nparams = off;
+  a->nparams = (off + 3) & ~(size_t)3;
   a->batch = c.num_envs * c.num_steps / c.num_mini_batches;
   a->max_rows = a->batch > c.num_envs ? a->batch : c.num_envs;
   int mw = 0; size_t maxw = 0;
@@ -611,6 +613,16 @@ int64_t ppo_num_params(const PpoConfig* cfg) {
   if (ppo_check_cfg(cfg)) return -1;
   PpoAlg a; a.cfg = *cfg; ppo_plan(&a);
   return (int64_t)a.nparams;
+}
+int32_t ppo_param_offsets(const PpoConfig* cfg, int64_t* offsets, int32_t max_entries) {
+  if (ppo_check_cfg(cfg)) return -1;
+  PpoAlg a; a.cfg = *cfg; ppo_plan(&a);
+  int n = 0;
+  auto push = [&](size_t v) { if (offsets && n < max_entries) offsets[n] = (int64_t)v; ++n; };
+  for (int i = 0; i < a.actor.nl; ++i) { push(a.actor.l[i].w); push(a.actor.l[i].b); }
+  for (int i = 0; i < a.critic.nl; ++i) { push(a.critic.l[i].w); push(a.critic.l[i].b); }
+  push(a.std_off);
+  return n;
 }
 int64_t ppo_workspace_floats(const PpoConfig* cfg) {
   if (ppo_check_cfg(cfg)) return -1;

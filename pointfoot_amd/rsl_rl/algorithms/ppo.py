@@ -83,7 +83,10 @@ class PPO:
         z = lambda n, dt=torch.float32: torch.zeros(n, device=dev, dtype=dt)
         self.params = z(P)
         ac.to(dev)
-        assert ac.flatten_into(self.params) == P
+        offs = (C.c_int64 * 32)()
+        nt = lib.ppo_param_offsets(C.byref(c), offs, 32)
+        self.param_offsets = [int(offs[i]) for i in range(nt)]
+        assert len(ac.kernel_order()) == nt and ac.flatten_into(self.params, self.param_offsets) <= P
         dp.sync_params(self.params)                   # identical initial policy on every rank
         self.grads = z(P + 4)                         # tail: [P] = KL sum, [P+1] = sample count
         self.adam_m, self.adam_v = z(P), z(P)
@@ -167,10 +170,7 @@ class PPO:
     def optimizer_state_dict(self):
         """torch.optim.Adam-compatible layout, parameters in `actor_critic.parameters()` order (std first)."""
         order = list(self.actor_critic.parameters())
-        offs, o = {}, 0
-        for p in self.actor_critic.kernel_order():
-            offs[id(p)] = (o, p.numel(), p.shape)
-            o += p.numel()
+        offs = {id(p): (o, p.numel(), p.shape) for p, o in zip(self.actor_critic.kernel_order(), self.param_offsets)}
         state = {}
         for i, p in enumerate(order):
             a, n, shp = offs[id(p)]
@@ -183,10 +183,7 @@ class PPO:
 
     def load_optimizer_state_dict(self, sd):
         order = list(self.actor_critic.parameters())
-        offs, o = {}, 0
-        for p in self.actor_critic.kernel_order():
-            offs[id(p)] = (o, p.numel())
-            o += p.numel()
+        offs = {id(p): (o, p.numel()) for p, o in zip(self.actor_critic.kernel_order(), self.param_offsets)}
         for i, p in enumerate(order):
             s = sd["state"].get(i)
             if s is None:

@@ -60,18 +60,22 @@ class ActorCritic(nn.Module):
                     ps += [m.weight, m.bias]
         return ps + [self.std]
 
-    def flatten_into(self, flat):
-        """Re-home every parameter as a view of `flat` (1-D float32 tensor on the target device)."""
-        off = 0
+    def flatten_into(self, flat, offsets=None):
+        """Re-home every parameter as a view of `flat` (1-D float32 tensor on the target device).  `offsets`: start of
+        each tensor in `kernel_order()` (from `ppo_param_offsets`: 16-byte aligned); None = packed."""
+        off, end = 0, 0
         with torch.no_grad():
-            for p in self.kernel_order():
+            for i, p in enumerate(self.kernel_order()):
                 n = p.numel()
+                if offsets is not None:
+                    off = offsets[i]
                 view = flat[off:off + n].view(p.shape)
                 view.copy_(p.data.to(flat.device))
                 p.data = view
                 off += n
+                end = max(end, off)
         self.flat = flat
-        return off
+        return end
 
     # ---- rsl_rl surface (torch path: used for export / inference on arbitrary devices) -----------------------
     def reset(self, dones=None):

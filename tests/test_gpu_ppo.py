@@ -27,7 +27,7 @@ def make(N, T, O, P, A, hidden, seed=0):
     alg = PPO(ac, device="cuda:0", **ALG)
     alg.init_storage(N, T, [O], [P], [A])
     ref = ppo_ref.RefActorCritic(O, P, A, hidden, hidden).to("cuda:0")
-    ref.load_flat(alg.params)
+    ref.load_flat(alg.params, alg.param_offsets)
     return alg, ref
 
 
@@ -89,7 +89,7 @@ def test_rollout_gae_and_full_update_match_autograd(N, T, O, P, A, hidden):
     loss, kl, vl, sl = ppo_ref.minibatch_loss(ref, mb, ALG["clip_param"], ALG["value_loss_coef"], ALG["entropy_coef"])
     ref.zero_grad()
     loss.backward()
-    g_ref = ref.flat_grad()
+    g_ref = ref.flat_grad(alg.param_offsets, alg.num_params)
     g = alg.grads[:alg.num_params]
     scale = g_ref.abs().max().item()
     assert (g - g_ref).abs().max().item() <= 2e-4 * scale + 1e-7, ((g - g_ref).abs().max().item(), scale)
@@ -106,7 +106,7 @@ def test_rollout_gae_and_full_update_match_autograd(N, T, O, P, A, hidden):
         torch.randperm = orig
     torch.cuda.synchronize()
     assert abs(alg.current_learning_rate.item() - lr) <= 1e-9 + 1e-6 * lr, (alg.current_learning_rate.item(), lr)
-    p_ref = ref.flat()
+    p_ref = ref.flat(alg.param_offsets, alg.num_params)
     err = (alg.params - p_ref).abs().max().item()
     assert err <= 3e-4, err
     assert abs(v_loss.item() - mv) <= 1e-3 * max(1.0, abs(mv)) and abs(s_loss.item() - ms) <= 1e-3 * max(1.0, abs(ms))
@@ -138,7 +138,7 @@ def test_full_size_minibatch_gradient():
     mb = {k: v[perm[2 * B:3 * B].long()] for k, v in store.items()}
     loss, kl, _, _ = ppo_ref.minibatch_loss(ref, mb, ALG["clip_param"], ALG["value_loss_coef"], ALG["entropy_coef"])
     ref.zero_grad(); loss.backward()
-    g_ref, g = ref.flat_grad(), alg.grads[:alg.num_params]
+    g_ref, g = ref.flat_grad(alg.param_offsets, alg.num_params), alg.grads[:alg.num_params]
     scale = g_ref.abs().max().item()
     assert (g - g_ref).abs().max().item() <= 3e-4 * scale, ((g - g_ref).abs().max().item(), scale)
     # determinism: a second launch gives bit-identical gradients (atomic-free reductions)
