@@ -184,6 +184,38 @@ __global__ void k_reduce_slabs(int n, int S, const float* __restrict__ slabs, fl
   if (sl == 0 && i < n) out[i] = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
 }
 
+// same reduction, four columns per thread (n % 4 == 0, 16-byte aligned slabs and output): dwordx4 loads
+__global__ void k_reduce_slabs4(int n4, int S, const float4* __restrict__ slabs, float4* __restrict__ out) {
+  __shared__ float4 sm[4][64];
+  int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  int i = blockIdx.x * 64 + col;
+  float4 a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add = [](float4& x, const float4& y) { x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; };
+  if (i < n4) {
+    int k = sl;
+    for (; k + 12 < S; k += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(a[u], slabs[(size_t)(k + 4 * u) * n4 + i]);
+    }
+    for (; k < S; k += 4) add(a[0], slabs[(size_t)k * n4 + i]);
+  }
+  add(a[0], a[1]); add(a[2], a[3]); add(a[0], a[2]);
+  sm[sl][col] = a[0];
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    float4 r = sm[0][col]; add(r, sm[1][col]); float4 q = sm[2][col]; add(q, sm[3][col]); add(r, q);
+    out[i] = r;
+  }
+}
+static inline void reduce_slabs(int n, int S, const float* slabs, float* out, hipStream_t s) {
+  if ((n & 3) == 0 && ((((size_t)slabs) | ((size_t)out)) & 15) == 0)
+    hipLaunchKernelGGL(k_reduce_slabs4, dim3((n / 4 + 63) / 64), dim3(256), 0, s, n / 4, S, (const float4*)slabs, (float4*)out);
+  else
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 63) / 64), dim3(256), 0, s, n, S, slabs, out);
+}
+
 // ------------------------------------------------------------------------------------- minibatch gather
 struct GatherJob { const float* src; float* dst; int cols; };
 struct GatherArgs { GatherJob job[9]; int njobs; };
@@ -447,6 +479,8 @@ static int ppo_check_cfg(const PpoConfig* c) {
     long long widest = c->num_obs > c->num_critic_obs ? c->num_obs : c->num_critic_obs;
     if (rows * widest >= (1ll << 31)) { pf_set_error("ppo: minibatch rows * obs width must stay below 2^31"); return 1; }
   }
+  for (int i = 1; i < c->n_actor_layers; ++i) if (c->actor_dims[i] & 3) { pf_set_error("ppo: hidden widths must be multiples of 4"); return 1; }
+  for (int i = 1; i < c->n_critic_layers; ++i) if (c->critic_dims[i] & 3) { pf_set_error("ppo: hidden widths must be multiples of 4"); return 1; }
   for (int i = 1; i < c->n_actor_layers; ++i) if (c->actor_dims[i] > 1024) { pf_set_error("ppo: hidden width > 1024"); return 1; }
   for (int i = 1; i < c->n_critic_layers; ++i) if (c->critic_dims[i] > 1024) { pf_set_error("ppo: hidden width > 1024"); return 1; }
   return 0;
@@ -526,7 +560,7 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
                        g_of(last - 1), hslabs);
     side_after(last);
     int nw = L.out * L.in + L.out;       // W then b, contiguous in the flat gradient buffer
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, sd, nw, nblk, hslabs, G + L.w);
+    reduce_slabs(nw, nblk, hslabs, G + L.w, sd);
   }
   for (int i = last - 1; i >= 0; --i) {
     const Layer& L = n.l[i];
@@ -553,7 +587,7 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
       else if (tile == 1) pf_gemm_launch<128, 64, false, false, GEMM_EPI_NONE, true>(g, S, sd);
       else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE, true>(g, S, sd);
       int nw = L.out * L.in + L.out;
-      hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, sd, nw, S, slabs, G + L.w);
+      reduce_slabs(nw, S, slabs, G + L.w, sd);
     }
     if (i > 0) side_after(i);     // the next layer's weight gradient needs g[i-1], produced by the GEMM just queued on s
   }
@@ -603,7 +637,7 @@ int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, 
     g.k_per_split = per;
     run(F{}, F{}, std::integral_constant<int, GEMM_EPI_NONE>{}, T{}, S);
     int nw = M * N + M;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((nw + 63) / 64), dim3(256), 0, s, nw, S, ws, Cm);
+    reduce_slabs(nw, S, ws, Cm, s);
   }
   PPO_HIP_OK(hipGetLastError());
   return 0;
@@ -762,7 +796,7 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
     const int cols[9] = {O, P, A, 1, A, A, 1, 1, 1};
     for (int i = 0; i < 9; ++i) ga.job[i] = GatherJob{srcs[i], ws + dsts[i], cols[i]};
     ga.njobs = 9;
-    hipLaunchKernelGGL(k_gather, dim3(240, 9), dim3(256), 0, s, B, perm, ga);
+    hipLaunchKernelGGL(k_gather, dim3(1024, 9), dim3(256), 0, s, B, perm, ga);
   }
   hipStream_t s2 = ppo_fork(a, s);
   mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s);
