@@ -209,7 +209,33 @@ __global__ void k_reduce_slabs4(int n4, int S, const float4* __restrict__ slabs,
     out[i] = r;
   }
 }
+// few columns, many slabs (the thin heads: n ~ 800, S ~ 800): 16 columns x 16 slab lanes per block
+__global__ void k_reduce_slabs_tall(int n, int S, const float* __restrict__ slabs, float* __restrict__ out) {
+  __shared__ float sm[16][17];
+  int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  int i = blockIdx.x * 16 + col;
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.0f;
+  if (i < n) {
+    int k = sl;
+    for (; k + 112 < S; k += 128) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += slabs[(size_t)(k + 16 * u) * n + i];
+    }
+    for (; k < S; k += 16) a[0] += slabs[(size_t)k * n + i];
+  }
+  sm[sl][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float t = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sm[j][col];
+    out[i] = t;
+  }
+}
 static inline void reduce_slabs(int n, int S, const float* slabs, float* out, hipStream_t s) {
+  if (n < 4096 && S >= 128) { hipLaunchKernelGGL(k_reduce_slabs_tall, dim3((n + 15) / 16), dim3(256), 0, s, n, S, slabs, out); return; }
   if ((n & 3) == 0 && ((((size_t)slabs) | ((size_t)out)) & 15) == 0)
     hipLaunchKernelGGL(k_reduce_slabs4, dim3((n / 4 + 63) / 64), dim3(256), 0, s, n / 4, S, (const float4*)slabs, (float4*)out);
   else
@@ -366,6 +392,199 @@ __global__ void k_loss(int B, int A, float clip, float vcoef, float ecoef, int c
   s = block_sum(sl, sm); if (threadIdx.x == 0) out[A + 2] = s;
   s = block_sum(en, sm); if (threadIdx.x == 0) out[A + 3] = s;
 }
+// Fused minibatch head: action-mean / value heads forward, the PPO loss of k_loss, and the heads' backward in ONE kernel
+// (replaces k_thin_fwd x2, k_loss, k_thin_bwd x2 and their launch gaps; 32 rows per block).
+//   phase 1 (8 lanes per row): mean = Ha Wa^T + ba, value = Hc Wc^T + bc, loss terms, dL/dmean, dL/dvalue -> LDS
+//   phase 2 (thread per hidden unit; threads 0..127 actor, 128..255 critic): Ga = (dmean Wa) * ELU'(Ha), Gc likewise,
+//            head weight / bias gradient partials of the block's rows -> slabs (reduced by k_reduce_slabs*)
+// partial[block][0..A+4) as k_loss.  Same formulas and summation structure as the separate kernels.
+constexpr int HEAD_ROWS = 32;
+__global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, float clip, float vcoef, float ecoef, int clipped_value,
+                                               const float* __restrict__ Ha, const float* __restrict__ Hc,
+                                               const float* __restrict__ Wa, const float* __restrict__ ba,
+                                               const float* __restrict__ Wc, const float* __restrict__ bc,
+                                               const float* __restrict__ stdp, const float* __restrict__ act,
+                                               const float* __restrict__ old_logp, const float* __restrict__ old_mu,
+                                               const float* __restrict__ old_sigma, const float* __restrict__ adv,
+                                               const float* __restrict__ ret, const float* __restrict__ old_val,
+                                               float* __restrict__ Ga, float* __restrict__ Gc, float* __restrict__ slabsA,
+                                               float* __restrict__ slabsC, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float hsm[];
+  float* sWa = hsm;                       // [A][Ka]
+  float* sWc = sWa + A * Ka;              // [Kc]
+  float* sD = sWc + Kc;                   // [HEAD_ROWS][A + 1]: dL/dmean, dL/dvalue of the block's rows
+  float* sP = sD + HEAD_ROWS * (A + 1);   // [4 waves][A + 4] loss partials
+  for (int i = threadIdx.x; i < A * Ka; i += 256) sWa[i] = Wa[i];
+  for (int i = threadIdx.x; i < Kc; i += 256) sWc[i] = Wc[i];
+  __syncthreads();
+  const int lane8 = threadIdx.x & 7, lr = threadIdx.x >> 3;
+  const int row = blockIdx.x * HEAD_ROWS + lr;
+  const bool rv = row < B;
+  const float invB = 1.0f / (float)B;
+  // ---- phase 1: heads forward (8 lanes per row; dwordx4 row reads when the widths allow)
+  float mu[16], val = 0.0f;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) mu[o] = 0.0f;
+  if (rv) {
+    if (((Ka | Kc) & 3) == 0) {
+      const float4* xr = reinterpret_cast<const float4*>(Ha + (size_t)row * Ka);
+      for (int k4 = lane8; k4 < (Ka >> 2); k4 += 8) {
+        float4 x = xr[k4];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) if (o < A) {
+          float4 w = *reinterpret_cast<const float4*>(&sWa[o * Ka + 4 * k4]);
+          mu[o] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+        }
+      }
+      const float4* cr = reinterpret_cast<const float4*>(Hc + (size_t)row * Kc);
+      for (int k4 = lane8; k4 < (Kc >> 2); k4 += 8) {
+        float4 x = cr[k4], w = *reinterpret_cast<const float4*>(&sWc[4 * k4]);
+        val += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+      }
+    } else {
+      for (int k = lane8; k < Ka; k += 8) {
+        float x = Ha[(size_t)row * Ka + k];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) if (o < A) mu[o] += x * sWa[o * Ka + k];
+      }
+      for (int k = lane8; k < Kc; k += 8) val += Hc[(size_t)row * Kc + k] * sWc[k];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 16; ++o) if (o < A) {
+    float v = mu[o];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    mu[o] = v + ba[o];
+  }
+  val += __shfl_xor(val, 1, 64); val += __shfl_xor(val, 2, 64); val += __shfl_xor(val, 4, 64);
+  val += bc[0];
+  // ---- loss (k_loss formulas); lane8 == 0 of each row does the per-sample scalar work
+  float dstd[16], kl = 0.0f, vl = 0.0f, sl = 0.0f, en = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dstd[k] = 0.0f;
+  if (rv && lane8 == 0) {
+    const int i = row;
+    float lp = 0.0f, kls = 0.0f, ens = 0.0f;
+    float dmu[16], dsg[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k < A) {
+      float m = mu[k], sg = stdp[k], a = act[(size_t)i * A + k];
+      float d = a - m;
+      lp += -0.5f * (d * d) / (sg * sg) - logf(sg) - 0.91893853320467274178f;
+      dmu[k] = d / (sg * sg);
+      dsg[k] = (d * d) / (sg * sg * sg) - 1.0f / sg;
+      float om = old_mu[(size_t)i * A + k], os = old_sigma[(size_t)i * A + k];
+      kls += logf(sg / os + 1e-5f) + (os * os + (om - m) * (om - m)) / (2.0f * sg * sg) - 0.5f;
+      ens += 0.5f + 0.91893853320467274178f + logf(sg);
+    }
+    float ad = adv[i];
+    float ratio = expf(lp - old_logp[i]);
+    float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+    float g_lp = (s1 >= s2) ? (-ad * ratio) * invB : 0.0f;
+    sl = fmaxf(s1, s2);
+    float v = val, r = ret[i], gv;
+    if (clipped_value) {
+      float ov = old_val[i];
+      float vc = ov + fminf(fmaxf(v - ov, -clip), clip);
+      float e1 = (v - r) * (v - r), e2 = (vc - r) * (vc - r);
+      bool inside = fabsf(v - ov) < clip;
+      gv = (e1 >= e2 || inside) ? 2.0f * (v - r) : 0.0f;
+      vl = fmaxf(e1, e2);
+    } else { gv = 2.0f * (v - r); vl = (r - v) * (r - v); }
+    sD[lr * (A + 1) + A] = vcoef * gv * invB;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k < A) { sD[lr * (A + 1) + k] = g_lp * dmu[k]; dstd[k] = g_lp * dsg[k]; }
+    kl = kls; en = ens;
+  } else if (lane8 == 0) {
+    for (int k = 0; k <= A; ++k) sD[lr * (A + 1) + k] = 0.0f;      // rows past the batch contribute nothing
+  }
+  // block partials: wave sums (fixed shuffle tree) -> LDS -> thread 0 adds the four waves in order
+  {
+    const int w = threadIdx.x >> 6;
+    auto wsum = [](float v) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      return v;
+    };
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k < A) { float t = wsum(dstd[k]); if ((threadIdx.x & 63) == 0) sP[w * (A + 4) + k] = t; }
+    float t;
+    t = wsum(kl); if ((threadIdx.x & 63) == 0) sP[w * (A + 4) + A] = t;
+    t = wsum(vl); if ((threadIdx.x & 63) == 0) sP[w * (A + 4) + A + 1] = t;
+    t = wsum(sl); if ((threadIdx.x & 63) == 0) sP[w * (A + 4) + A + 2] = t;
+    t = wsum(en); if ((threadIdx.x & 63) == 0) sP[w * (A + 4) + A + 3] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < A + 4) {
+    const int c = threadIdx.x;
+    partial[(size_t)blockIdx.x * (A + 4) + c] = (sP[c] + sP[(A + 4) + c]) + (sP[2 * (A + 4) + c] + sP[3 * (A + 4) + c]);
+  }
+  // ---- phase 2: heads backward, thread per hidden unit
+  const int r0 = blockIdx.x * HEAD_ROWS, nr = min(HEAD_ROWS, B - r0);
+  if (threadIdx.x < 128) {
+    float* sl_out = slabsA + (size_t)blockIdx.x * ((size_t)A * Ka + A);
+    for (int k = threadIdx.x; k < Ka; k += 128) {
+      float w[16], dw[16];
+#pragma unroll
+      for (int o = 0; o < 16; ++o) { w[o] = o < A ? sWa[o * Ka + k] : 0.0f; dw[o] = 0.0f; }
+      int r = 0;
+      for (; r + 8 <= nr; r += 8) {
+        float h[8], g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { h[u] = Ha[(size_t)(r0 + r + u) * Ka + k]; g[u] = 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int o = 0; o < 16; ++o) if (o < A) { float d = sD[(r + u) * (A + 1) + o]; g[u] += d * w[o]; dw[o] += d * h[u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) Ga[(size_t)(r0 + r + u) * Ka + k] = g[u] * (h[u] > 0.0f ? 1.0f : h[u] + 1.0f);
+      }
+      for (; r < nr; ++r) {
+        float h = Ha[(size_t)(r0 + r) * Ka + k], g = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) if (o < A) { float d = sD[r * (A + 1) + o]; g += d * w[o]; dw[o] += d * h; }
+        Ga[(size_t)(r0 + r) * Ka + k] = g * (h > 0.0f ? 1.0f : h + 1.0f);
+      }
+#pragma unroll
+      for (int o = 0; o < 16; ++o) if (o < A) sl_out[(size_t)o * Ka + k] = dw[o];
+    }
+    if (threadIdx.x < A) {        // bias gradient = column sums of dL/dmean over the block's rows
+      float db = 0.0f;
+      for (int r = 0; r < nr; ++r) db += sD[r * (A + 1) + threadIdx.x];
+      sl_out[(size_t)A * Ka + threadIdx.x] = db;
+    }
+  } else {
+    const int t = threadIdx.x - 128;
+    float* sl_out = slabsC + (size_t)blockIdx.x * ((size_t)Kc + 1);
+    for (int k = t; k < Kc; k += 128) {
+      const float w = sWc[k];
+      float dw = 0.0f;
+      int r = 0;
+      for (; r + 8 <= nr; r += 8) {
+        float h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) h[u] = Hc[(size_t)(r0 + r + u) * Kc + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float d = sD[(r + u) * (A + 1) + A];
+          dw += d * h[u];
+          Gc[(size_t)(r0 + r + u) * Kc + k] = d * w * (h[u] > 0.0f ? 1.0f : h[u] + 1.0f);
+        }
+      }
+      for (; r < nr; ++r) {
+        float h = Hc[(size_t)(r0 + r) * Kc + k], d = sD[r * (A + 1) + A];
+        dw += d * h;
+        Gc[(size_t)(r0 + r) * Kc + k] = d * w * (h > 0.0f ? 1.0f : h + 1.0f);
+      }
+      sl_out[k] = dw;
+    }
+    if (t == 0) {
+      float db = 0.0f;
+      for (int r = 0; r < nr; ++r) db += sD[r * (A + 1) + A];
+      sl_out[Kc] = db;
+    }
+  }
+}
 // finish the loss reductions: dL/dstd (incl. the entropy bonus), KL sum + count for the adaptive LR
 __global__ void k_loss_finish(int nb, int A, int B, float ecoef, const float* __restrict__ partial, const float* __restrict__ stdp,
                               float* __restrict__ dstd, float* __restrict__ grads_tail, float* __restrict__ scalars) {
@@ -373,7 +592,18 @@ __global__ void k_loss_finish(int nb, int A, int B, float ecoef, const float* __
   __shared__ float sm[8][33];
   int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   float s = 0.0f;
-  if (c < A + 4) for (int b = r; b < nb; b += 8) s += partial[(size_t)b * (A + 4) + c];
+  if (c < A + 4) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = 0.0f;
+    int b = r;
+    for (; b + 56 < nb; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] += partial[(size_t)(b + 8 * u) * (A + 4) + c];
+    }
+    for (; b < nb; b += 8) t[0] += partial[(size_t)b * (A + 4) + c];
+    s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  }
   sm[r][c] = s;
   __syncthreads();
   if (r == 0 && c < A + 4) {
@@ -451,7 +681,7 @@ struct PpoAlg {
   hipStream_t side[2] = {nullptr, nullptr};   // per network: weight-gradient GEMMs + slab reduces run beside the data-gradient chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_side[2][PPO_MAX_LAYERS + 1] = {}, ev_side_done[2] = {nullptr, nullptr};
-  bool dual = true, use_side = false;
+  bool dual = true, use_side = false, fused_heads = true;
   int max_rows = 0, max_width = 0, splits = 0;
 };
 
@@ -512,19 +742,20 @@ static void ppo_plan(PpoAlg* a) {
   for (int k = 0; k < 2; ++k) for (int l = 0; l < PPO_MAX_LAYERS; ++l) a->w_g[k][l] = take(R * mw);
   size_t thin_blocks = (R + 31) / 32;
   for (int k = 0; k < 2; ++k) a->w_slabs[k] = take(std::max<size_t>((size_t)a->splits * (maxw + mw), thin_blocks * (16 * 1024 + 16)));
-  a->w_partial = take((size_t)RED_BLOCKS * 24);
+  a->w_partial = take(std::max<size_t>((size_t)RED_BLOCKS * 24, thin_blocks * 20));
   a->w_lastval = take(c.num_envs);
   a->w_total = w;
 }
 
 // forward through one MLP: X[M, in0] -> activations; hidden layers on the MFMA GEMM (bias + ELU fused), head on the thin kernel
-static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, hipStream_t s) {
+static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, hipStream_t s, bool with_head = true) {
   float* ws = a->b.d_workspace; const float* P = a->b.d_params;
   const float* in = X;
   for (int i = 0; i < n.nl; ++i) {
     const Layer& L = n.l[i];
     float* out = ws + w_h[i];
     if (i == n.nl - 1) {
+      if (!with_head) break;          // the minibatch path runs both heads inside k_heads
       int threads = 256, rows_per_block = threads / 8;
       hipLaunchKernelGGL((k_thin_fwd<16>), dim3((M + rows_per_block - 1) / rows_per_block), dim3(threads), sizeof(float) * L.out * L.in, s,
                          M, L.in, L.out, in, P + L.w, P + L.b, out);
@@ -538,6 +769,7 @@ static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const si
 }
 
 // backward through one MLP given dHead[M, out_last]; writes weight/bias gradients into d_grads
+// (dHead == nullptr: k_heads already wrote g[last-1] and the head's gradient slabs; only their reduction is left)
 static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, const float* dHead, hipStream_t s, int set) {
   float* ws = a->b.d_workspace; const float* P = a->b.d_params; float* G = a->b.d_grads;
   float* slabs = ws + a->w_slabs[set];
@@ -556,8 +788,9 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
     int rows_per_block = 32, nblk = (M + rows_per_block - 1) / rows_per_block;
     int threads = (L.in + 63) / 64 * 64;
     float* hslabs = slabs + (size_t)a->splits * 0;      // head slabs share the buffer: the side stream runs in order
-    hipLaunchKernelGGL((k_thin_bwd<16>), dim3(nblk), dim3(threads), 0, s, M, L.in, L.out, rows_per_block, dHead, ws + w_h[last - 1], P + L.w,
-                       g_of(last - 1), hslabs);
+    if (dHead)
+      hipLaunchKernelGGL((k_thin_bwd<16>), dim3(nblk), dim3(threads), 0, s, M, L.in, L.out, rows_per_block, dHead, ws + w_h[last - 1], P + L.w,
+                         g_of(last - 1), hslabs);
     side_after(last);
     int nw = L.out * L.in + L.out;       // W then b, contiguous in the flat gradient buffer
     reduce_slabs(nw, nblk, hslabs, G + L.w, sd);
@@ -669,6 +902,7 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
   PpoAlg* a = new PpoAlg();
   a->cfg = *cfg; a->device = device;
   ppo_plan(a);
+  if (const char* fh = getenv("PF_PPO_FUSED_HEADS")) a->fused_heads = atoi(fh) != 0;
   const char* e = getenv("PF_PPO_DUAL_STREAM");
   a->dual = e ? atoi(e) != 0 : true;
   const char* e2 = getenv("PF_PPO_SIDE_STREAMS");
@@ -799,18 +1033,40 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
     hipLaunchKernelGGL(k_gather, dim3(1024, 9), dim3(256), 0, s, B, perm, ga);
   }
   hipStream_t s2 = ppo_fork(a, s);
-  mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s);
-  mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s2);
-  ppo_join(a, s, s2);
   const float* stdp = a->b.d_params + a->std_off;
-  hipLaunchKernelGGL(k_loss, dim3(RED_BLOCKS), dim3(256), 0, s, B, A, c.clip_param, c.value_loss_coef, c.entropy_coef, c.use_clipped_value_loss,
-                     ws + a->w_ha[a->actor.nl - 1], ws + a->w_hc[a->critic.nl - 1], stdp, ws + a->w_act, ws + a->w_oldlogp, ws + a->w_oldmu,
-                     ws + a->w_oldsig, ws + a->w_adv, ws + a->w_ret, ws + a->w_oldval, ws + a->w_dmean, ws + a->w_dvalue, ws + a->w_partial);
-  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, RED_BLOCKS, A, B, c.entropy_coef, ws + a->w_partial, stdp,
-                     a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
-  s2 = ppo_fork(a, s);
-  mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, ws + a->w_dmean, s, 0);
-  mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, ws + a->w_dvalue, s2, 1);
+  const Layer& La = a->actor.l[a->actor.nl - 1];
+  const Layer& Lc = a->critic.l[a->critic.nl - 1];
+  if (a->fused_heads) {
+    // hidden layers on the GEMM, then both heads + loss + head backward in one kernel
+    mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s, false);
+    mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s2, false);
+    ppo_join(a, s, s2);
+    const int nblk = (B + HEAD_ROWS - 1) / HEAD_ROWS;
+    const size_t lds = sizeof(float) * ((size_t)A * La.in + Lc.in + HEAD_ROWS * (A + 1) + 4 * (A + 4));
+    hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(256), lds, s, B, A, La.in, Lc.in, c.clip_param, c.value_loss_coef, c.entropy_coef,
+                       c.use_clipped_value_loss, ws + a->w_ha[a->actor.nl - 2], ws + a->w_hc[a->critic.nl - 2], a->b.d_params + La.w,
+                       a->b.d_params + La.b, a->b.d_params + Lc.w, a->b.d_params + Lc.b, stdp, ws + a->w_act, ws + a->w_oldlogp,
+                       ws + a->w_oldmu, ws + a->w_oldsig, ws + a->w_adv, ws + a->w_ret, ws + a->w_oldval,
+                       ws + a->w_g[0][a->actor.nl - 2], ws + a->w_g[1][a->critic.nl - 2], ws + a->w_slabs[0], ws + a->w_slabs[1],
+                       ws + a->w_partial);
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, nblk, A, B, c.entropy_coef, ws + a->w_partial, stdp,
+                       a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
+    s2 = ppo_fork(a, s);
+    mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, nullptr, s, 0);
+    mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, nullptr, s2, 1);
+  } else {
+    mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s);
+    mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s2);
+    ppo_join(a, s, s2);
+    hipLaunchKernelGGL(k_loss, dim3(RED_BLOCKS), dim3(256), 0, s, B, A, c.clip_param, c.value_loss_coef, c.entropy_coef, c.use_clipped_value_loss,
+                       ws + a->w_ha[a->actor.nl - 1], ws + a->w_hc[a->critic.nl - 1], stdp, ws + a->w_act, ws + a->w_oldlogp, ws + a->w_oldmu,
+                       ws + a->w_oldsig, ws + a->w_adv, ws + a->w_ret, ws + a->w_oldval, ws + a->w_dmean, ws + a->w_dvalue, ws + a->w_partial);
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, RED_BLOCKS, A, B, c.entropy_coef, ws + a->w_partial, stdp,
+                       a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
+    s2 = ppo_fork(a, s);
+    mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, ws + a->w_dmean, s, 0);
+    mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, ws + a->w_dvalue, s2, 1);
+  }
   ppo_join(a, s, s2);
   PPO_HIP_OK(hipGetLastError());
   return 0;
