@@ -7,7 +7,7 @@
  * Two parts:
  *  (1) the reference's PYTHON LAYER, restated line by line from
  *      /root/reference/legged_gym/envs/pointfoot/point_foot.py (cited per function below) in float32
- *      with the same operation order (compile with -ffp-contract=off).  PINNED by tests/golden/*.npz,
+ *      with the same operation order (compile with -ffp-contract=off).  PINNED by the .npz files in tests/golden,
  *      which were produced by running the reference's own PointFoot methods (tests/golden/make_golden.py).
  *  (2) the PHYSICS substep the reference delegates to Isaac Gym / PhysX (point_foot.py:183, closed
  *      binary, absent): an own floating-base articulated-body step (world-frame CRBA + RNEA, Cholesky,
@@ -748,9 +748,10 @@ void post_physics(const Ctx& x, int env, float* S) {
         for (int k = 0; k < nd; ++k) sm += std::fabs(S[L.dof_pos + k] - c.default_dof_pos[k]);
         float cn = std::sqrt(S[L.commands] * S[L.commands] + S[L.commands + 1] * S[L.commands + 1]);
         v = sm * (cn < 0.1f ? 1.0f : 0.0f);
-      } else
+      } else {
         v = (std::fabs(S[L.base_lin_vel]) * (S[L.commands] < 0.1f ? 1.0f : 0.0f) + std::fabs(S[L.base_lin_vel + 1]) * (S[L.commands + 1] < 0.1f ? 1.0f : 0.0f)) +
             std::fabs(S[L.base_ang_vel + 2]) * (S[L.commands + 2] < 0.1f ? 1.0f : 0.0f);
+      }
         break;
       case PF_REW_FEET_CONTACT_FORCES:
         for (int f = 0; f < nf; ++f) { const float* F = S + L.contact_forces + 3 * m.feet_body[f]; v += std::max(std::sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]) - c.max_contact_force, 0.0f); }
