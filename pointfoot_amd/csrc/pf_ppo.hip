@@ -86,6 +86,94 @@ __global__ void k_sample(int N, int A, int O, int P, const float* __restrict__ o
   s_val[i] = value[i]; s_logp[i] = lp;
 }
 
+// k_thin_fwd (both heads) + k_sample in one launch for the rollout: 8 lanes per env compute the action means and the
+// value from the last hidden activations, then lane k of the group draws action dimension k (same Philox keys as k_sample).
+__global__ __launch_bounds__(256) void k_act_heads(int N, int A, int O, int P, int Ka, int Kc, const float* __restrict__ obs,
+                                                   const float* __restrict__ cobs, const float* __restrict__ Ha,
+                                                   const float* __restrict__ Hc, const float* __restrict__ Wa,
+                                                   const float* __restrict__ ba, const float* __restrict__ Wc,
+                                                   const float* __restrict__ bc, const float* __restrict__ stdp,
+                                                   const float* __restrict__ inject_normal, uint32_t k0, uint32_t k1, uint32_t counter,
+                                                   uint32_t env_base, float* __restrict__ actions_out, float* __restrict__ s_obs,
+                                                   float* __restrict__ s_cobs, float* __restrict__ s_act, float* __restrict__ s_val,
+                                                   float* __restrict__ s_logp, float* __restrict__ s_mu, float* __restrict__ s_sigma) {
+  extern __shared__ __attribute__((aligned(16))) float asm_[];
+  float* sWa = asm_;               // [A][Ka]
+  float* sWc = sWa + A * Ka;       // [Kc]
+  for (int i = threadIdx.x; i < A * Ka; i += 256) sWa[i] = Wa[i];
+  for (int i = threadIdx.x; i < Kc; i += 256) sWc[i] = Wc[i];
+  {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x, gs = (size_t)gridDim.x * 256;
+    for (size_t j = g; j < (size_t)N * O; j += gs) s_obs[j] = obs[j];
+    for (size_t j = g; j < (size_t)N * P; j += gs) s_cobs[j] = cobs[j];
+  }
+  __syncthreads();
+  const int lane8 = threadIdx.x & 7;
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (i >= N) return;                 // whole 8-lane groups leave together (shuffles below stay inside a group)
+  float mu[16], val = 0.0f;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) mu[o] = 0.0f;
+  if (((Ka | Kc) & 3) == 0) {
+    const float4* xr = reinterpret_cast<const float4*>(Ha + (size_t)i * Ka);
+    for (int k4 = lane8; k4 < (Ka >> 2); k4 += 8) {
+      float4 x = xr[k4];
+#pragma unroll
+      for (int o = 0; o < 16; ++o) if (o < A) {
+        float4 w = *reinterpret_cast<const float4*>(&sWa[o * Ka + 4 * k4]);
+        mu[o] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+      }
+    }
+    const float4* cr = reinterpret_cast<const float4*>(Hc + (size_t)i * Kc);
+    for (int k4 = lane8; k4 < (Kc >> 2); k4 += 8) {
+      float4 x = cr[k4], w = *reinterpret_cast<const float4*>(&sWc[4 * k4]);
+      val += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+    }
+  } else {
+    for (int k = lane8; k < Ka; k += 8) {
+      float x = Ha[(size_t)i * Ka + k];
+#pragma unroll
+      for (int o = 0; o < 16; ++o) if (o < A) mu[o] += x * sWa[o * Ka + k];
+    }
+    for (int k = lane8; k < Kc; k += 8) val += Hc[(size_t)i * Kc + k] * sWc[k];
+  }
+#pragma unroll
+  for (int o = 0; o < 16; ++o) if (o < A) {
+    float v = mu[o];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    mu[o] = v + ba[o];
+  }
+  val += __shfl_xor(val, 1, 64); val += __shfl_xor(val, 2, 64); val += __shfl_xor(val, 4, 64);
+  val += bc[0];
+  float lp = 0.0f;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int k = lane8 + 8 * kk;
+    if (k < A) {
+      float z;
+      if (inject_normal) z = inject_normal[(size_t)i * A + k];
+      else {
+        uint32_t r[4];
+        philox4(env_base + (uint32_t)i, counter, 1u, (uint32_t)k, k0, k1, r);
+        float u1 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+        float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+        z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+      }
+      float m = 0.0f;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) if (o == k) m = mu[o];     // register select (mu[] is indexed by constants only)
+      float sg = stdp[k];
+      float a = m + sg * z;
+      float d = (a - m) / sg;
+      lp += -0.5f * d * d - logf(sg) - 0.91893853320467274178f;
+      actions_out[(size_t)i * A + k] = a;
+      s_act[(size_t)i * A + k] = a; s_mu[(size_t)i * A + k] = m; s_sigma[(size_t)i * A + k] = sg;
+    }
+  }
+  lp += __shfl_xor(lp, 1, 64); lp += __shfl_xor(lp, 2, 64); lp += __shfl_xor(lp, 4, 64);
+  if (lane8 == 0) { s_val[i] = val; s_logp[i] = lp; }
+}
+
 // PPO.process_env_step: bootstrap on time-outs, store reward / done
 __global__ void k_process(int N, float gamma, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
                           const uint8_t* __restrict__ time_outs, const float* __restrict__ s_val, float* __restrict__ s_rew,
@@ -955,14 +1043,28 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   const int N = c.num_envs, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   float* ws = a->b.d_workspace;
   hipStream_t s2 = ppo_fork(a, s);
-  mlp_forward(a, a->actor, d_obs, N, a->w_ha, s);
-  mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s2);
-  ppo_join(a, s, s2);
   size_t tn = (size_t)t * N;
-  hipLaunchKernelGGL(k_sample, dim3(std::max((N + 255) / 256, 512)), dim3(256), 0, s, N, A, O, P, d_obs, d_critic_obs, ws + a->w_ha[a->actor.nl - 1],
-                     ws + a->w_hc[a->critic.nl - 1], a->b.d_params + a->std_off, d_inject_normal, c.seed_lo, c.seed_hi, (uint32_t)sample_counter,
-                     0u, d_actions_out, a->b.d_obs + tn * O, a->b.d_critic_obs + tn * P, a->b.d_actions + tn * A, a->b.d_values + tn,
-                     a->b.d_log_prob + tn, a->b.d_mu + tn * A, a->b.d_sigma + tn * A);
+  if (a->fused_heads) {
+    mlp_forward(a, a->actor, d_obs, N, a->w_ha, s, false);
+    mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s2, false);
+    ppo_join(a, s, s2);
+    const Layer& La = a->actor.l[a->actor.nl - 1];
+    const Layer& Lc = a->critic.l[a->critic.nl - 1];
+    hipLaunchKernelGGL(k_act_heads, dim3(std::max((N + 31) / 32, 512)), dim3(256), sizeof(float) * ((size_t)A * La.in + Lc.in), s, N, A, O, P,
+                       La.in, Lc.in, d_obs, d_critic_obs, ws + a->w_ha[a->actor.nl - 2], ws + a->w_hc[a->critic.nl - 2],
+                       a->b.d_params + La.w, a->b.d_params + La.b, a->b.d_params + Lc.w, a->b.d_params + Lc.b,
+                       a->b.d_params + a->std_off, d_inject_normal, c.seed_lo, c.seed_hi, (uint32_t)sample_counter, 0u, d_actions_out,
+                       a->b.d_obs + tn * O, a->b.d_critic_obs + tn * P, a->b.d_actions + tn * A, a->b.d_values + tn, a->b.d_log_prob + tn,
+                       a->b.d_mu + tn * A, a->b.d_sigma + tn * A);
+  } else {
+    mlp_forward(a, a->actor, d_obs, N, a->w_ha, s);
+    mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s2);
+    ppo_join(a, s, s2);
+    hipLaunchKernelGGL(k_sample, dim3(std::max((N + 255) / 256, 512)), dim3(256), 0, s, N, A, O, P, d_obs, d_critic_obs, ws + a->w_ha[a->actor.nl - 1],
+                       ws + a->w_hc[a->critic.nl - 1], a->b.d_params + a->std_off, d_inject_normal, c.seed_lo, c.seed_hi, (uint32_t)sample_counter,
+                       0u, d_actions_out, a->b.d_obs + tn * O, a->b.d_critic_obs + tn * P, a->b.d_actions + tn * A, a->b.d_values + tn,
+                       a->b.d_log_prob + tn, a->b.d_mu + tn * A, a->b.d_sigma + tn * A);
+  }
   PPO_HIP_OK(hipGetLastError());
   return 0;
 }
