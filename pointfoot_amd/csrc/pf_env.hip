@@ -27,14 +27,18 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // touches its own record, so no inter-workgroup ordering is needed.
 // model / cfg are separate __restrict__ const kernel arguments so the compiler can prove they are invariant and
 // read them with scalar loads (s_load) into SGPRs instead of holding hundreds of config values in VGPRs.
-template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH>
+template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1>
 __global__ __launch_bounds__(64, WAVES) void pf_step_kernel(const PfModel* __restrict__ model, const PfConfig* __restrict__ cfg, PfStepArgs g) {
-  using K = PfKernel<NB, ND, NF, KIND, KS>;
-  __shared__ typename K::Shared sh;
+  using K = PfKernel<NB, ND, NF, KIND, KS, RPW>;
+  __shared__ typename K::Shared sh[RPW];
   g.model = model; g.cfg = cfg;
   // the slot the *next* launch accumulates into is cleared here, so a rollout needs no memset between steps
   if (blockIdx.x == 0 && g.stats_next && threadIdx.x < PF_STATS_FLOATS) g.stats_next[threadIdx.x] = 0.0f;
-  K::run(sh, g, (int)blockIdx.x);
+  // RPW robots per wavefront: each group of 64 / RPW lanes runs the phase program on its own robot and its own LDS block
+  const int part = (int)threadIdx.x / (64 / RPW);
+  const int env = (int)blockIdx.x * RPW + part;
+  if (env >= cfg->num_envs) return;
+  K::run(sh[part], g, env);
 }
 
 struct PfEnv {
@@ -186,10 +190,15 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
     g.stats_next = (e->stats_next && e->stats_next != e->bufs.d_reset_stats) ? e->stats_next : nullptr;
     e->stats_cleared = g.stats_next;
   }
-  // PF_STEP_WAVES selects the register budget variant (waves per SIMD the kernel is compiled for)
+  // PF_STEP_RPW: robots per wavefront for the PointFoot instance (2: one per 32-lane half, 256-VGPR budget, default);
+  // PF_STEP_WAVES: register budget variant of the one-robot-per-wave kernel (waves per SIMD it is compiled for)
+  static const int rpw = [] { const char* v = getenv("PF_STEP_RPW"); return v ? atoi(v) : 2; }();
   static const int variant = [] { const char* v = getenv("PF_STEP_WAVES"); return v ? atoi(v) : 4; }();
-  dim3 grid(e->cfg.num_envs), block(64);
+  const int N = e->cfg.num_envs;
+  dim3 grid(N), block(64);
   if (e->instance == 1) hipLaunchKernelGGL((pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>), grid, block, 0, s, e->d_model, e->d_cfg, g);
+  else if (rpw == 2) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2>), dim3((N + 1) / 2), block, 0, s, e->d_model, e->d_cfg, g);
+  else if (rpw == 4) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 1, PF_KIND_POINTFOOT, PF_KSPH, 4>), dim3((N + 3) / 4), block, 0, s, e->d_model, e->d_cfg, g);
   else if (variant == 4) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 4>), grid, block, 0, s, e->d_model, e->d_cfg, g);
   else if (variant == 3) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 3>), grid, block, 0, s, e->d_model, e->d_cfg, g);
   else hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 2>), grid, block, 0, s, e->d_model, e->d_cfg, g);

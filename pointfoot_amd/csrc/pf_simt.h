@@ -1,6 +1,6 @@
 // pf_simt.h — the small SIMT vocabulary the env-step kernel is written in.
 //
-// One wavefront (64 lanes) owns one robot.  The kernel is a *phase program*: lane-strided loops
+// One wavefront (64 lanes) owns one robot, or each 32-lane half owns one (PF_W).  The kernel is a *phase program*: lane-strided loops
 // (PF_LANES) that touch only their own items, separated by PF_SYNC(), plus "uniform" sections that
 // every lane executes redundantly (all branches on env state are wave-uniform because a wave holds
 // exactly one env).  Shared data lives in LDS.
@@ -27,15 +27,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #define PF_DEV static __device__ __forceinline__
-#define PF_LANES(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
+// PF_W = lanes per robot: a constexpr in scope at every use (PfKernel::PF_W).  64: one robot per wavefront; 32: two robots
+// per wavefront, one per half -- uniform sections and loops over <= 32 items then cost one instruction for two robots.
+#define PF_LANE_ID ((int)threadIdx.x & (PF_W - 1))
+#define PF_LANES(i, n) for (int i = PF_LANE_ID; i < (n); i += PF_W)
 #define PF_SYNC() __syncthreads()
-#define PF_ONE if (threadIdx.x == 0)
+#define PF_ONE if (PF_LANE_ID == 0)
+template <int W>
 PF_DEV float pf_wave_sum(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-#define PF_WAVE_SUM(x) pf_wave_sum(x)
+#define PF_WAVE_SUM(x) pf_wave_sum<PF_W>(x)
 #define PF_ATOMIC_ADD(p, v) atomicAdd((p), (v))
-#define PF_LANE_ID ((int)threadIdx.x)
 #endif

@@ -128,8 +128,9 @@ struct PfStepArgs {
   float* stats_next;      // next step's statistics slot, cleared by this launch (NULL: the host clears slots itself)
 };
 
-template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH>
+template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1>
 struct PfKernel {
+  static constexpr int PF_W = 64 / RPW;         // lanes per robot (pf_simt.h)
   static constexpr bool LR = KIND == PF_KIND_LEGGED_ROBOT;      // LeggedRobot / Anymal semantics (legged_robot.py)
   static constexpr int REC_MAX = LR ? 704 : PF_REC_MAX;
   static constexpr int NV = 6 + ND;
