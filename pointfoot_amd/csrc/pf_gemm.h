@@ -44,13 +44,15 @@ __device__ __forceinline__ float pf_elu(float x) { return x > 0.0f ? x : (__expf
 // of its next tile's first k-slice, so the C-tile write (with bias/ELU) and the next tile's load latency overlap instead
 // of adding up.  Tile numbers are remapped so the eight XCDs (round-robin over workgroup ids, one L2 each) each own a
 // contiguous range of tiles: blocks that share A rows / B columns hit the same L2.
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false, bool VEC = true>
-__global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
-  constexpr int BK = 32;
+constexpr int PF_GEMM_BK = 32;
+constexpr int PF_GEMM_LDS_S = PF_GEMM_BK + 4;      // LDS row stride (floats): 16 B aligned rows, conflict-free b128 fragment reads
+// The kernel body: block `bid` of `nblk` blocks working on problem `g` (so one launch can carry two problems, see
+// pf_gemm_kernel2); As / Bs are the workgroup's LDS tiles (BM x LDS_S and BN x LDS_S floats).
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool VEC>
+__device__ __forceinline__ void pf_gemm_body(const GemmArgs& g, const int bid, const int nblk, float* __restrict__ As, float* __restrict__ Bs) {
+  constexpr int BK = PF_GEMM_BK;
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int LDS_S = BK + 4;      // row stride (floats): 16 B aligned rows, conflict-free b128 fragment reads
-  __shared__ __attribute__((aligned(16))) float As[BM * LDS_S];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_S];
+  constexpr int LDS_S = PF_GEMM_LDS_S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_x = (g.N + BN - 1) / BN, tiles_y = (g.M + BM - 1) / BM;
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
   };
 
   Tile cur;
-  int t = blockIdx.x;
-  while (t < tmax && !decode(t, cur)) t += gridDim.x;
+  int t = bid;
+  while (t < tmax && !decode(t, cur)) t += nblk;
   if (t >= tmax) return;
   fetch(cur, cur.k_begin);
   const int arow = wr * (BM / 2) + (lane & 31), bcol = wc * (BN / 2) + (lane & 31), kh = lane >> 5;
@@ -185,9 +187,9 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
     }
     // next tile of this block: get its first k-slice in flight before the write-out below
     Tile nxt;
-    int tn = t + gridDim.x;
+    int tn = t + nblk;
     bool more = false;
-    while (tn < tmax) { if (decode(tn, nxt)) { more = true; break; } tn += gridDim.x; }
+    while (tn < tmax) { if (decode(tn, nxt)) { more = true; break; } tn += nblk; }
     if (more) fetch(nxt, nxt.k_begin);
 
     if (COLSUM && cur.bx == 0 && tid < BM && cur.m0 + tid < g.M) cur.C[(size_t)g.M * g.ldc + cur.m0 + tid] = csum;
@@ -215,23 +217,63 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
   }
 }
 
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false, bool VEC = true>
+__global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[BM * PF_GEMM_LDS_S];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * PF_GEMM_LDS_S];
+  pf_gemm_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC>(g, (int)blockIdx.x, (int)gridDim.x, As, Bs);
+}
+// Two independent problems of the same arrangement in one launch (the actor's and the critic's layer i): blocks
+// [0, nb0) work on g0, the rest on g1.  One grid instead of two streams: the tails of one problem are filled by the other
+// without cross-stream events.  nb0 is a multiple of 8 so the XCD of a block is the same function of its local id.
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool VEC0, bool VEC1>
+__global__ __launch_bounds__(256) void pf_gemm_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
+  __shared__ __attribute__((aligned(16))) float As[BM * PF_GEMM_LDS_S];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * PF_GEMM_LDS_S];
+  if ((int)blockIdx.x < nb0) pf_gemm_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC0>(g0, (int)blockIdx.x, nb0, As, Bs);
+  else pf_gemm_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC1>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, As, Bs);
+}
+
 // PF_GEMM_PERSIST = resident blocks per CU for the persistent grid (0: one block per tile)
 static inline int pf_gemm_persist() { static const int v = [] { const char* e = getenv("PF_GEMM_PERSIST"); return e ? atoi(e) : 0; }(); return v; }
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
-static inline void pf_gemm_launch(const GemmArgs& g_in, int splits, hipStream_t s) {
-  GemmArgs g = g_in;
+template <int BM, int BN>
+static inline int pf_gemm_blocks(GemmArgs& g, int splits) {
   g.nsplit = splits > 0 ? splits : 1;
   int ntiles = ((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM) * g.nsplit;
   int blocks = (ntiles + 7) / 8 * 8;
   int p = pf_gemm_persist();
   if (p > 0 && blocks > p * 256) blocks = p * 256;
-  // float4 row loads of the k-contiguous operands need 16 B aligned rows and K % 4 == 0
+  return blocks;
+}
+// float4 row loads of the k-contiguous operands need 16 B aligned rows and K % 4 == 0
+template <bool A_KC, bool B_KC>
+static inline bool pf_gemm_vec(const GemmArgs& g) {
+  if (!A_KC && !B_KC) return true;      // no k-contiguous operand: one instance
   bool vec = (g.K & 3) == 0;
   if (A_KC) vec = vec && ((((size_t)g.A) & 15) == 0) && ((g.lda & 3) == 0);
   if (B_KC) vec = vec && ((((size_t)g.B) & 15) == 0) && ((g.ldb & 3) == 0);
-  if (!A_KC && !B_KC) vec = true;      // no k-contiguous operand: one instance
-  if (vec) hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, true>), dim3(blocks), dim3(256), 0, s, g);
+  return vec;
+}
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
+static inline void pf_gemm_launch(const GemmArgs& g_in, int splits, hipStream_t s) {
+  GemmArgs g = g_in;
+  const int blocks = pf_gemm_blocks<BM, BN>(g, splits);
+  if (pf_gemm_vec<A_KC, B_KC>(g)) hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, true>), dim3(blocks), dim3(256), 0, s, g);
   else hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, (A_KC || B_KC) ? false : true>), dim3(blocks), dim3(256), 0, s, g);
+}
+// two problems, one launch (64x64 tiles)
+template <bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
+static inline void pf_gemm_launch2(const GemmArgs& g0_in, int splits0, const GemmArgs& g1_in, int splits1, hipStream_t s) {
+  GemmArgs g0 = g0_in, g1 = g1_in;
+  const int nb0 = pf_gemm_blocks<64, 64>(g0, splits0), nb1 = pf_gemm_blocks<64, 64>(g1, splits1);
+  const bool v0 = pf_gemm_vec<A_KC, B_KC>(g0), v1 = pf_gemm_vec<A_KC, B_KC>(g1);
+  constexpr bool HAS_KC = A_KC || B_KC;
+  const dim3 grid(nb0 + nb1), block(256);
+  if (v0 && v1) hipLaunchKernelGGL((pf_gemm_kernel2<64, 64, A_KC, B_KC, EPI, COLSUM, true, true>), grid, block, 0, s, g0, g1, nb0);
+  else if (!v0 && v1) hipLaunchKernelGGL((pf_gemm_kernel2<64, 64, A_KC, B_KC, EPI, COLSUM, HAS_KC ? false : true, true>), grid, block, 0, s, g0, g1, nb0);
+  else if (v0 && !v1) hipLaunchKernelGGL((pf_gemm_kernel2<64, 64, A_KC, B_KC, EPI, COLSUM, true, HAS_KC ? false : true>), grid, block, 0, s, g0, g1, nb0);
+  else hipLaunchKernelGGL((pf_gemm_kernel2<64, 64, A_KC, B_KC, EPI, COLSUM, HAS_KC ? false : true, HAS_KC ? false : true>), grid, block, 0, s, g0, g1, nb0);
 }
 
 // Tile choice from a small cost model calibrated on MI355X (tools/gemm_bench.py): the main loop runs at the matrix
@@ -265,6 +307,15 @@ static inline void pf_pick_split(int M, int N, int K, int max_splits, int* tile_
   *tile_out = 2; *splits_out = S < 1 ? 1 : S;
 }
 template <bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
+static inline void pf_gemm_auto(const GemmArgs& g, int splits, hipStream_t s);
+// the pair in one launch when both problems want 64x64 tiles (every PPO shape does), else one launch each
+template <bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
+static inline void pf_gemm_auto2(const GemmArgs& g0, int splits0, const GemmArgs& g1, int splits1, hipStream_t s) {
+  if (pf_pick_tile(g0.M, g0.N, g0.K, splits0) == 2 && pf_pick_tile(g1.M, g1.N, g1.K, splits1) == 2)
+    pf_gemm_launch2<A_KC, B_KC, EPI, COLSUM>(g0, splits0, g1, splits1, s);
+  else { pf_gemm_auto<A_KC, B_KC, EPI, COLSUM>(g0, splits0, s); pf_gemm_auto<A_KC, B_KC, EPI, COLSUM>(g1, splits1, s); }
+}
+template <bool A_KC, bool B_KC, int EPI, bool COLSUM>
 static inline void pf_gemm_auto(const GemmArgs& g, int splits, hipStream_t s) {
   switch (pf_pick_tile(g.M, g.N, g.K, splits)) {
     case 0: pf_gemm_launch<128, 128, A_KC, B_KC, EPI, COLSUM>(g, splits, s); break;

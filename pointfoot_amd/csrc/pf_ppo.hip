@@ -251,10 +251,10 @@ __global__ void k_normalize(size_t n, float* __restrict__ x, float* __restrict__
 // out[i] = sum_s slabs[s][i].  Block = 64 consecutive outputs x 4 slab lanes (each lane sums every 4th slab with two
 // independent accumulators), combined through LDS in a fixed order: deterministic, 4x the parallelism of one thread
 // per output and short dependent-load chains.
-__global__ void k_reduce_slabs(int n, int S, const float* __restrict__ slabs, float* __restrict__ out) {
+__device__ __forceinline__ void reduce_body(int n, int S, const float* __restrict__ slabs, float* __restrict__ out, int bid) {
   __shared__ float sm[4][64];
   int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  int i = blockIdx.x * 64 + col;
+  int i = bid * 64 + col;
   float a[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) a[u] = 0.0f;
@@ -271,12 +271,11 @@ __global__ void k_reduce_slabs(int n, int S, const float* __restrict__ slabs, fl
   __syncthreads();
   if (sl == 0 && i < n) out[i] = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
 }
-
 // same reduction, four columns per thread (n % 4 == 0, 16-byte aligned slabs and output): dwordx4 loads
-__global__ void k_reduce_slabs4(int n4, int S, const float4* __restrict__ slabs, float4* __restrict__ out) {
+__device__ __forceinline__ void reduce4_body(int n4, int S, const float4* __restrict__ slabs, float4* __restrict__ out, int bid) {
   __shared__ float4 sm[4][64];
   int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  int i = blockIdx.x * 64 + col;
+  int i = bid * 64 + col;
   float4 a[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -298,10 +297,10 @@ __global__ void k_reduce_slabs4(int n4, int S, const float4* __restrict__ slabs,
   }
 }
 // few columns, many slabs (the thin heads: n ~ 800, S ~ 800): 16 columns x 16 slab lanes per block
-__global__ void k_reduce_slabs_tall(int n, int S, const float* __restrict__ slabs, float* __restrict__ out) {
+__device__ __forceinline__ void reduce_tall_body(int n, int S, const float* __restrict__ slabs, float* __restrict__ out, int bid) {
   __shared__ float sm[16][17];
   int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  int i = blockIdx.x * 16 + col;
+  int i = bid * 16 + col;
   float a[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) a[u] = 0.0f;
@@ -322,12 +321,31 @@ __global__ void k_reduce_slabs_tall(int n, int S, const float* __restrict__ slab
     out[i] = t;
   }
 }
+// one split-K slab reduction: out[i] = sum_s slabs[s][i], fixed order.  kind 0: 64 columns per block; 1: 256 columns per
+// block as float4; 2: 16 columns x 16 slab lanes (few columns, many slabs)
+struct ReduceJob { int n, S, kind, blocks; const float* slabs; float* out; };
+__device__ __forceinline__ void reduce_job(const ReduceJob& j, int bid) {
+  if (j.kind == 1) reduce4_body(j.n / 4, j.S, (const float4*)j.slabs, (float4*)j.out, bid);
+  else if (j.kind == 2) reduce_tall_body(j.n, j.S, j.slabs, j.out, bid);
+  else reduce_body(j.n, j.S, j.slabs, j.out, bid);
+}
+__global__ __launch_bounds__(256) void k_reduce_slabs(ReduceJob j) { reduce_job(j, (int)blockIdx.x); }
+// two reductions in one launch (the actor's and the critic's layer i)
+__global__ __launch_bounds__(256) void k_reduce_slabs2(ReduceJob j0, ReduceJob j1) {
+  if ((int)blockIdx.x < j0.blocks) reduce_job(j0, (int)blockIdx.x); else reduce_job(j1, (int)blockIdx.x - j0.blocks);
+}
+static inline ReduceJob reduce_plan(int n, int S, const float* slabs, float* out) {
+  ReduceJob j{n, S, 0, (n + 63) / 64, slabs, out};
+  if (n < 4096 && S >= 128) { j.kind = 2; j.blocks = (n + 15) / 16; }
+  else if ((n & 3) == 0 && ((((size_t)slabs) | ((size_t)out)) & 15) == 0) { j.kind = 1; j.blocks = (n / 4 + 63) / 64; }
+  return j;
+}
 static inline void reduce_slabs(int n, int S, const float* slabs, float* out, hipStream_t s) {
-  if (n < 4096 && S >= 128) { hipLaunchKernelGGL(k_reduce_slabs_tall, dim3((n + 15) / 16), dim3(256), 0, s, n, S, slabs, out); return; }
-  if ((n & 3) == 0 && ((((size_t)slabs) | ((size_t)out)) & 15) == 0)
-    hipLaunchKernelGGL(k_reduce_slabs4, dim3((n / 4 + 63) / 64), dim3(256), 0, s, n / 4, S, (const float4*)slabs, (float4*)out);
-  else
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 63) / 64), dim3(256), 0, s, n, S, slabs, out);
+  ReduceJob j = reduce_plan(n, S, slabs, out);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(j.blocks), dim3(256), 0, s, j);
+}
+static inline void reduce_slabs2(const ReduceJob& j0, const ReduceJob& j1, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_slabs2, dim3(j0.blocks + j1.blocks), dim3(256), 0, s, j0, j1);
 }
 
 // ------------------------------------------------------------------------------------- minibatch gather
@@ -770,6 +788,7 @@ struct PpoAlg {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_side[2][PPO_MAX_LAYERS + 1] = {}, ev_side_done[2] = {nullptr, nullptr};
   bool dual = true, use_side = false, fused_heads = true;
+  bool paired = true;      // actor + critic layer i in one launch (needs fused_heads and equal depth); else two streams
   int max_rows = 0, max_width = 0, splits = 0;
 };
 
@@ -915,6 +934,68 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
   if (sd != s) { (void)hipEventRecord(a->ev_side_done[set], sd); (void)hipStreamWaitEvent(s, a->ev_side_done[set], 0); }
 }
 
+// ---- paired execution: layer i of the actor and of the critic go out as ONE launch (pf_gemm_kernel2 / k_reduce_slabs2).
+// Same overlap as two streams -- one problem's tail blocks are filled by the other's -- without cross-stream events
+// (each costs ~10 us on the critical path) and with half the launches.  Needs the same number of layers in both nets.
+static GemmArgs fwd_args(PpoAlg* a, const Net& n, int i, const float* in, const size_t* w_h, int M) {
+  const Layer& L = n.l[i];
+  GemmArgs g{};
+  g.A = in; g.B = a->b.d_params + L.w; g.C = a->b.d_workspace + w_h[i]; g.M = M; g.N = L.out; g.K = L.in; g.lda = L.in; g.ldb = L.in; g.ldc = L.out;
+  g.bias = a->b.d_params + L.b;
+  return g;
+}
+static void mlp_forward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s) {
+  float* ws = a->b.d_workspace;
+  const float *ina = Xa, *inc = Xc;
+  for (int i = 0; i + 1 < a->actor.nl; ++i) {       // hidden layers; the heads run in k_heads / k_act_heads
+    GemmArgs ga = fwd_args(a, a->actor, i, ina, a->w_ha, M), gc = fwd_args(a, a->critic, i, inc, a->w_hc, M);
+    pf_gemm_auto2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);     // the larger problem (critic) first
+    ina = ws + a->w_ha[i]; inc = ws + a->w_hc[i];
+  }
+}
+static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s) {
+  float* ws = a->b.d_workspace; const float* P = a->b.d_params; float* G = a->b.d_grads;
+  const Net* net[2] = {&a->actor, &a->critic};
+  const size_t* w_h[2] = {a->w_ha, a->w_hc};
+  const float* X[2] = {Xa, Xc};
+  const int last = a->actor.nl - 1;
+  auto g_of = [&](int set, int i) { return ws + a->w_g[set][i]; };
+  {   // head gradient slabs written by k_heads
+    const int nblk = (M + HEAD_ROWS - 1) / HEAD_ROWS;
+    ReduceJob j[2];
+    for (int k = 0; k < 2; ++k) { const Layer& L = net[k]->l[last]; j[k] = reduce_plan(L.out * L.in + L.out, nblk, ws + a->w_slabs[k], G + L.w); }
+    reduce_slabs2(j[0], j[1], s);
+  }
+  for (int i = last - 1; i >= 0; --i) {
+    if (i > 0) {      // dZ_{i-1} = (g_i W_i) * ELU'(h_{i-1})
+      GemmArgs g[2];
+      for (int k = 0; k < 2; ++k) {
+        const Layer& L = net[k]->l[i];
+        g[k] = GemmArgs{};
+        g[k].A = g_of(k, i); g[k].B = P + L.w; g[k].C = g_of(k, i - 1); g[k].M = M; g[k].N = L.in; g[k].K = L.out;
+        g[k].lda = L.out; g[k].ldb = L.in; g[k].ldc = L.in; g[k].H = ws + w_h[k][i - 1]; g[k].ldh = L.in;
+      }
+      pf_gemm_auto2<true, false, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
+    }
+    // dW_i, db_i as split-K slabs, then the deterministic slab reduce straight into the flat gradient
+    GemmArgs g[2]; int S[2]; ReduceJob j[2];
+    for (int k = 0; k < 2; ++k) {
+      const Layer& L = net[k]->l[i];
+      g[k] = GemmArgs{};
+      g[k].A = g_of(k, i); g[k].B = i == 0 ? X[k] : ws + w_h[k][i - 1]; g[k].C = ws + a->w_slabs[k];
+      g[k].M = L.out; g[k].N = L.in; g[k].K = M; g[k].lda = L.out; g[k].ldb = L.in; g[k].ldc = L.in;
+      int tile, want;
+      pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
+      int per = ((M + want - 1) / want + 31) / 32 * 32;
+      S[k] = (M + per - 1) / per;
+      g[k].k_per_split = per;
+      j[k] = reduce_plan(L.out * L.in + L.out, S[k], ws + a->w_slabs[k], G + L.w);
+    }
+    pf_gemm_launch2<false, false, GEMM_EPI_NONE, true>(g[1], S[1], g[0], S[0], s);
+    reduce_slabs2(j[1], j[0], s);
+  }
+}
+
 // The actor and the critic are independent networks: run the critic on a second stream so one network's launch tails,
 // prologues and epilogues overlap the other's main loops (both are matrix-pipe bound; the gain is in the gaps).
 static hipStream_t ppo_fork(PpoAlg* a, hipStream_t s) {
@@ -991,6 +1072,8 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
   a->cfg = *cfg; a->device = device;
   ppo_plan(a);
   if (const char* fh = getenv("PF_PPO_FUSED_HEADS")) a->fused_heads = atoi(fh) != 0;
+  if (const char* pr = getenv("PF_PPO_PAIRED")) a->paired = atoi(pr) != 0;
+  a->paired = a->paired && a->fused_heads && a->actor.nl == a->critic.nl;
   const char* e = getenv("PF_PPO_DUAL_STREAM");
   a->dual = e ? atoi(e) != 0 : true;
   const char* e2 = getenv("PF_PPO_SIDE_STREAMS");
@@ -1042,12 +1125,15 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   hipStream_t s = (hipStream_t)stream;
   const int N = c.num_envs, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   float* ws = a->b.d_workspace;
-  hipStream_t s2 = ppo_fork(a, s);
+  hipStream_t s2 = a->paired ? s : ppo_fork(a, s);
   size_t tn = (size_t)t * N;
   if (a->fused_heads) {
-    mlp_forward(a, a->actor, d_obs, N, a->w_ha, s, false);
-    mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s2, false);
-    ppo_join(a, s, s2);
+    if (a->paired) mlp_forward_pair(a, d_obs, d_critic_obs, N, s);
+    else {
+      mlp_forward(a, a->actor, d_obs, N, a->w_ha, s, false);
+      mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s2, false);
+      ppo_join(a, s, s2);
+    }
     const Layer& La = a->actor.l[a->actor.nl - 1];
     const Layer& Lc = a->critic.l[a->critic.nl - 1];
     hipLaunchKernelGGL(k_act_heads, dim3(std::max((N + 31) / 32, 512)), dim3(256), sizeof(float) * ((size_t)A * La.in + Lc.in), s, N, A, O, P,
@@ -1134,15 +1220,18 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
     ga.njobs = 9;
     hipLaunchKernelGGL(k_gather, dim3(1024, 9), dim3(256), 0, s, B, perm, ga);
   }
-  hipStream_t s2 = ppo_fork(a, s);
+  hipStream_t s2 = a->paired ? s : ppo_fork(a, s);
   const float* stdp = a->b.d_params + a->std_off;
   const Layer& La = a->actor.l[a->actor.nl - 1];
   const Layer& Lc = a->critic.l[a->critic.nl - 1];
   if (a->fused_heads) {
     // hidden layers on the GEMM, then both heads + loss + head backward in one kernel
-    mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s, false);
-    mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s2, false);
-    ppo_join(a, s, s2);
+    if (a->paired) mlp_forward_pair(a, ws + a->w_xa, ws + a->w_xc, B, s);
+    else {
+      mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s, false);
+      mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s2, false);
+      ppo_join(a, s, s2);
+    }
     const int nblk = (B + HEAD_ROWS - 1) / HEAD_ROWS;
     const size_t lds = sizeof(float) * ((size_t)A * La.in + Lc.in + HEAD_ROWS * (A + 1) + 4 * (A + 4));
     hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(256), lds, s, B, A, La.in, Lc.in, c.clip_param, c.value_loss_coef, c.entropy_coef,
@@ -1153,9 +1242,12 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
                        ws + a->w_partial);
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, nblk, A, B, c.entropy_coef, ws + a->w_partial, stdp,
                        a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
-    s2 = ppo_fork(a, s);
-    mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, nullptr, s, 0);
-    mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, nullptr, s2, 1);
+    if (a->paired) mlp_backward_pair(a, ws + a->w_xa, ws + a->w_xc, B, s);
+    else {
+      s2 = ppo_fork(a, s);
+      mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, nullptr, s, 0);
+      mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, nullptr, s2, 1);
+    }
   } else {
     mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s);
     mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s2);
