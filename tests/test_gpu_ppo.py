@@ -73,8 +73,16 @@ def ref_store(alg):
                 old_log_prob=f(st.actions_log_prob)[:, 0], old_mu=f(st.mu), old_sigma=f(st.sigma))
 
 
+# execution variants of the same arithmetic (read by ppo_create): default = actor and critic layers paired in one launch +
+# fused head kernels; the fallbacks run the critic on a second stream / the separate head, loss and sampling kernels
+VARIANTS = [{}, {"PF_PPO_PAIRED": "0"}, {"PF_PPO_FUSED_HEADS": "0"}, {"PF_PPO_FUSED_HEADS": "0", "PF_PPO_DUAL_STREAM": "0"}]
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "+".join(f"{k[7:]}={x}" for k, x in v.items()) or "default")
 @pytest.mark.parametrize("N,T,O,P,A,hidden", [(96, 8, 27, 27, 6, [128, 64, 32]), (160, 6, 27, 148, 6, [512, 256, 128])])
-def test_rollout_gae_and_full_update_match_autograd(N, T, O, P, A, hidden):
+def test_rollout_gae_and_full_update_match_autograd(N, T, O, P, A, hidden, variant, monkeypatch):
+    for k, v in variant.items():
+        monkeypatch.setenv(k, v)
     alg, ref = make(N, T, O, P, A, hidden)
     gen = torch.Generator(device="cuda:0").manual_seed(1)
     fill_rollout(alg, ref, N, T, O, P, A, gen)
