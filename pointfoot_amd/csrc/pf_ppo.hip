@@ -784,10 +784,8 @@ struct PpoAlg {
   size_t w_ha[PPO_MAX_LAYERS], w_hc[PPO_MAX_LAYERS];   // activations per layer output (last = head output)
   size_t w_dmean, w_dvalue, w_g[2][PPO_MAX_LAYERS], w_slabs[2], w_partial, w_lastval, w_total;   // [0] actor / [1] critic scratch (run concurrently)
   hipStream_t aux = nullptr;        // second stream: the critic network runs beside the actor network
-  hipStream_t side[2] = {nullptr, nullptr};   // per network: weight-gradient GEMMs + slab reduces run beside the data-gradient chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  hipEvent_t ev_side[2][PPO_MAX_LAYERS + 1] = {}, ev_side_done[2] = {nullptr, nullptr};
-  bool dual = true, use_side = false, fused_heads = true;
+  bool dual = true, fused_heads = true;
   bool paired = true;      // actor + critic layer i in one launch (needs fused_heads and equal depth); else two streams
   int max_rows = 0, max_width = 0, splits = 0;
 };
@@ -881,40 +879,34 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
   float* ws = a->b.d_workspace; const float* P = a->b.d_params; float* G = a->b.d_grads;
   float* slabs = ws + a->w_slabs[set];
   const int last = n.nl - 1;
-  // Weight gradients are off the critical path: they run on this network's side stream, ordered after the kernel that
-  // produced their input gradient (event per layer) and reusing one slab buffer in stream order; every layer has its own
-  // gradient buffer g[i] = dL/dz_i so the data-gradient chain never overwrites what a weight-gradient GEMM still reads.
-  // Measured on MI355X (pointfoot_rough, B = 24 576): actor||critic concurrency takes the update from 23.1 to 20.1 ms; putting
-  // the weight-gradient GEMMs on side streams as well adds nothing (20.5 ms), so it is off unless PF_PPO_SIDE_STREAMS=1.
-  hipStream_t sd = (a->dual && a->use_side && a->side[set]) ? a->side[set] : s;
+  // Every layer has its own gradient buffer g[i] = dL/dz_i.  (Putting the weight-gradient GEMMs on further side streams
+  // was measured and adds nothing: 20.5 vs 20.1 ms per update at the time.)
   auto g_of = [&](int i) { return ws + a->w_g[set][i]; };
-  auto side_after = [&](int i) { if (sd != s) { (void)hipEventRecord(a->ev_side[set][i], s); (void)hipStreamWaitEvent(sd, a->ev_side[set][i], 0); } };
-  // thin head: g[last-1] = dZ_{last-1}, dW_last, db_last (one kernel; its slab reduce goes to the side stream)
+  // thin head: g[last-1] = dZ_{last-1}, dW_last, db_last (one kernel), then its slab reduce
   {
     const Layer& L = n.l[last];
     int rows_per_block = 32, nblk = (M + rows_per_block - 1) / rows_per_block;
     int threads = (L.in + 63) / 64 * 64;
-    float* hslabs = slabs + (size_t)a->splits * 0;      // head slabs share the buffer: the side stream runs in order
+    float* hslabs = slabs;      // head slabs share the buffer: the stream runs in order
     if (dHead)
       hipLaunchKernelGGL((k_thin_bwd<16>), dim3(nblk), dim3(threads), 0, s, M, L.in, L.out, rows_per_block, dHead, ws + w_h[last - 1], P + L.w,
                          g_of(last - 1), hslabs);
-    side_after(last);
     int nw = L.out * L.in + L.out;       // W then b, contiguous in the flat gradient buffer
-    reduce_slabs(nw, nblk, hslabs, G + L.w, sd);
+    reduce_slabs(nw, nblk, hslabs, G + L.w, s);
   }
   for (int i = last - 1; i >= 0; --i) {
     const Layer& L = n.l[i];
     const float* in = i == 0 ? X : ws + w_h[i - 1];
     const float* gcur = g_of(i);
     if (i > 0) {
-      // dZ_{i-1} = (gcur[M,out] * W_i[out,in]) * ELU'(h_{i-1})      -- critical path, main stream
+      // dZ_{i-1} = (gcur[M,out] * W_i[out,in]) * ELU'(h_{i-1})
       GemmArgs g{};
       g.A = gcur; g.B = P + L.w; g.C = g_of(i - 1); g.M = M; g.N = L.in; g.K = L.out; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
       g.H = ws + w_h[i - 1]; g.ldh = L.in;
       pf_gemm_auto<true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
     }
     // dW_i = gcur[M, out]^T * in[M, in] and db_i = column sums of gcur, both as split-K slabs [S][out*in + out]
-    // (rows split across blockIdx.z; deterministic slab reduce straight into the flat gradient: W then b)  -- side stream
+    // (deterministic slab reduce straight into the flat gradient: W then b)
     {
       GemmArgs g{};
       g.A = gcur; g.B = in; g.C = slabs; g.M = L.out; g.N = L.in; g.K = M; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
@@ -923,15 +915,13 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
       int per = ((M + want - 1) / want + 31) / 32 * 32;
       int S = (M + per - 1) / per;
       g.k_per_split = per;
-      if (tile == 0) pf_gemm_launch<128, 128, false, false, GEMM_EPI_NONE, true>(g, S, sd);
-      else if (tile == 1) pf_gemm_launch<128, 64, false, false, GEMM_EPI_NONE, true>(g, S, sd);
-      else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE, true>(g, S, sd);
+      if (tile == 0) pf_gemm_launch<128, 128, false, false, GEMM_EPI_NONE, true>(g, S, s);
+      else if (tile == 1) pf_gemm_launch<128, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
+      else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
       int nw = L.out * L.in + L.out;
-      reduce_slabs(nw, S, slabs, G + L.w, sd);
+      reduce_slabs(nw, S, slabs, G + L.w, s);
     }
-    if (i > 0) side_after(i);     // the next layer's weight gradient needs g[i-1], produced by the GEMM just queued on s
   }
-  if (sd != s) { (void)hipEventRecord(a->ev_side_done[set], sd); (void)hipStreamWaitEvent(s, a->ev_side_done[set], 0); }
 }
 
 // ---- paired execution: layer i of the actor and of the critic go out as ONE launch (pf_gemm_kernel2 / k_reduce_slabs2).
@@ -1075,21 +1065,13 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
   if (const char* pr = getenv("PF_PPO_PAIRED")) a->paired = atoi(pr) != 0;
   a->paired = a->paired && a->fused_heads && a->actor.nl == a->critic.nl;
   const char* e = getenv("PF_PPO_DUAL_STREAM");
-  a->dual = e ? atoi(e) != 0 : true;
-  const char* e2 = getenv("PF_PPO_SIDE_STREAMS");
-  a->use_side = e2 ? atoi(e2) != 0 : false;
+  a->dual = (e ? atoi(e) != 0 : true) && !a->paired;      // the second stream is only used by the unpaired path
   if (a->dual) {
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming) != hipSuccess) {
       a->aux = nullptr; a->dual = false;     // no GPU visible (host-only use of ppo_num_params etc.): single stream
       (void)hipGetLastError();
-    } else {
-      for (int k = 0; k < 2; ++k) {
-        (void)hipStreamCreateWithFlags(&a->side[k], hipStreamNonBlocking);
-        (void)hipEventCreateWithFlags(&a->ev_side_done[k], hipEventDisableTiming);
-        for (int l = 0; l <= PPO_MAX_LAYERS; ++l) (void)hipEventCreateWithFlags(&a->ev_side[k][l], hipEventDisableTiming);
-      }
     }
   }
   return a;
@@ -1099,11 +1081,6 @@ void ppo_destroy(PpoAlg* a) {
   if (a->aux) (void)hipStreamDestroy(a->aux);
   if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
   if (a->ev_join) (void)hipEventDestroy(a->ev_join);
-  for (int k = 0; k < 2; ++k) {
-    if (a->side[k]) (void)hipStreamDestroy(a->side[k]);
-    if (a->ev_side_done[k]) (void)hipEventDestroy(a->ev_side_done[k]);
-    for (int l = 0; l <= PPO_MAX_LAYERS; ++l) if (a->ev_side[k][l]) (void)hipEventDestroy(a->ev_side[k][l]);
-  }
   delete a;
 }
 
