@@ -40,5 +40,18 @@ PF_DEV float pf_wave_sum(float v) {
   return v;
 }
 #define PF_WAVE_SUM(x) pf_wave_sum<PF_W>(x)
+// sum over the 16 lanes of a DPP row (quad swaps, half-row mirror, row mirror): four v_add_f32_dpp, and every lane ends
+// with the same bits because each lane adds the same pairs at every level
+template <int CTRL>
+PF_DEV float pf_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+PF_DEV float pf_row16_sum(float v) {
+  v += pf_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += pf_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += pf_dpp<0x141>(v);    // row_half_mirror
+  v += pf_dpp<0x140>(v);    // row_mirror
+  return v;
+}
 #define PF_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #endif

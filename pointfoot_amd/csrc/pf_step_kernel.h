@@ -646,6 +646,76 @@ struct PfKernel {
     // and are stored by all lanes with the same value (each lane later re-reads what it wrote), so the dependent
     // updates need no barrier; J and W rows are LDS broadcast reads.
     const float mu = 0.5f * (S[LC::friction] + c.terrain_friction);
+#if !defined(PF_HOST_EMU)
+    if constexpr (NV <= 16) {
+      // GPU form for <= 16 velocity components: lane t of each 16-lane DPP row owns v[t] and column t of every J / W row
+      // (loop-invariant, in registers with the impulses); a row's J.v is one multiply + a 4-step DPP butterfly whose result
+      // is bit-identical in all lanes (IEEE add is commutative and every lane walks the same tree), so the uniform impulse
+      // math stays consistent.  No LDS traffic inside the sweep except the broadcast reads of rb / 1/A / the Delassus block.
+      const int tl = PF_LANE_ID & 15;
+      const bool tv = tl < NV;
+      float v = tv ? sh.vel[tl] : 0.0f;
+      float jc[MAXC][3], wc[MAXC][3], lc[MAXC][3], jl[ND], wl[ND], ll[ND];
+#pragma unroll
+      for (int ci = 0; ci < MAXC; ++ci)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const bool on = ci < ncon;
+          jc[ci][d] = (on && tv) ? sh.J[3 * ci + d][tl] : 0.0f;
+          wc[ci][d] = (on && tv) ? sh.W[3 * ci + d][tl] : 0.0f;
+          lc[ci][d] = on ? sh.lam[3 * ci + d] : 0.0f;
+        }
+#pragma unroll
+      for (int li = 0; li < ND; ++li) {
+        const bool on = li < nlim;
+        jl[li] = (on && tv) ? sh.J[CROWS + li][tl] : 0.0f;
+        wl[li] = (on && tv) ? sh.W[CROWS + li][tl] : 0.0f;
+        ll[li] = on ? sh.lam[CROWS + li] : 0.0f;
+      }
+      for (int it = 0; it < c.solver_iterations; ++it) {
+#pragma unroll
+        for (int ci = 0; ci < MAXC; ++ci) {
+          if (ci < ncon) {
+            const int r0 = 3 * ci;
+            const float u0 = pf_row16_sum(jc[ci][0] * v), u1 = pf_row16_sum(jc[ci][1] * v), u2 = pf_row16_sum(jc[ci][2] * v);
+            const float l0 = lc[ci][0], l1o = lc[ci][1], l2o = lc[ci][2];
+            const float ln = fmaxf(0.0f, l0 + (sh.rb[r0] - u0) * sh.rAinv[r0]);
+            const float d0 = ln - l0;
+            const float u1c = u1 + sh.cA[ci][3] * d0;
+            float l1 = l1o - u1c * sh.rAinv[r0 + 1];
+            const float d1p = l1 - l1o;
+            const float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
+            float l2 = l2o - u2c * sh.rAinv[r0 + 2];
+            const float lim = mu * ln, nt = sqrtf(l1 * l1 + l2 * l2);
+            if (nt > lim) { float sc = nt > 0.0f ? lim / nt : 0.0f; l1 *= sc; l2 *= sc; }
+            const float d1 = l1 - l1o, d2 = l2 - l2o;
+            v += wc[ci][0] * d0 + wc[ci][1] * d1 + wc[ci][2] * d2;
+            lc[ci][0] = ln; lc[ci][1] = l1; lc[ci][2] = l2;
+          }
+        }
+#pragma unroll
+        for (int li = 0; li < ND; ++li) {
+          if (li < nlim) {
+            const int rr = CROWS + li;
+            const float u = pf_row16_sum(jl[li] * v);
+            const float lo = ll[li];
+            const float ln = fmaxf(0.0f, lo + (sh.rb[rr] - u) * sh.rAinv[rr]);
+            v += wl[li] * (ln - lo);
+            ll[li] = ln;
+          }
+        }
+      }
+      PF_SYNC();
+      if (PF_LANE_ID < NV) sh.vel[PF_LANE_ID] = v;
+      PF_ONE {
+#pragma unroll
+        for (int ci = 0; ci < MAXC; ++ci) if (ci < ncon) { sh.lam[3 * ci] = lc[ci][0]; sh.lam[3 * ci + 1] = lc[ci][1]; sh.lam[3 * ci + 2] = lc[ci][2]; }
+#pragma unroll
+        for (int li = 0; li < ND; ++li) if (li < nlim) sh.lam[CROWS + li] = ll[li];
+      }
+      PF_SYNC();
+    } else
+#endif
     {
       float v[NV];
 #pragma unroll
