@@ -139,6 +139,16 @@ struct PfKernel {
   static constexpr int CROWS = 3 * MAXC;
   static constexpr int RFREE = CROWS + ND;    // extra right-hand side: free acceleration
   static constexpr int NROWS = RFREE + 1;
+#if defined(PF_HOST_EMU)
+  static constexpr bool CHOLR = false;
+#else
+  // <= 12 velocity components: the Cholesky factor lives in registers (packed lower triangle, every lane holds all of it
+  // and factorises redundantly with static indices: no LDS round trips, no barriers), and the substitutions read it there
+  static constexpr bool CHOLR = NV <= 12;
+#endif
+  static constexpr int NLT = CHOLR ? NV * (NV + 1) / 2 : 1;
+  static constexpr int NDV = CHOLR ? NV : 1;
+  static constexpr int lt(int i, int t) { return i * (i + 1) / 2 + t; }
 
 
   // Record offsets as compile-time constants (same rule as pf_compute_layout with num_actions == ND; checked against the
@@ -513,20 +523,45 @@ struct PfKernel {
     }
     PF_SYNC();
     PF_STAMP(sh, 3);
-    // ---- in-place Cholesky, one column per phase
-    for (int j = 0; j < NV; ++j) {
-      float d = sh.M[j][j];
-      for (int t = 0; t < j; ++t) d -= sh.M[j][t] * sh.M[j][t];
-      d = sqrtf(fmaxf(d, 1e-12f));
-      float di = 1.0f / d;
-      PF_LANES(ii, NV - j - 1) {
-        int i = j + 1 + ii;
-        float s = sh.M[i][j];
-        for (int t = 0; t < j; ++t) s -= sh.M[i][t] * sh.M[j][t];
-        sh.M[i][j] = s * di;
+    // ---- Cholesky (same operation order in both forms)
+    float Lr[NLT], dv[NDV];
+    if constexpr (CHOLR) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int t = 0; t <= i; ++t) Lr[lt(i, t)] = sh.M[i][t];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        float d = Lr[lt(j, j)];
+#pragma unroll
+        for (int t = 0; t < j; ++t) d -= Lr[lt(j, t)] * Lr[lt(j, t)];
+        d = sqrtf(fmaxf(d, 1e-12f));
+        const float di = 1.0f / d;
+        dv[j] = di;
+#pragma unroll
+        for (int i = j + 1; i < NV; ++i) {
+          float sacc = Lr[lt(i, j)];
+#pragma unroll
+          for (int t = 0; t < j; ++t) sacc -= Lr[lt(i, t)] * Lr[lt(j, t)];
+          Lr[lt(i, j)] = sacc * di;
+        }
       }
-      PF_ONE { sh.dinv[j] = di; }
-      PF_SYNC();
+    } else {
+      // in place in LDS, one column per phase
+      for (int j = 0; j < NV; ++j) {
+        float d = sh.M[j][j];
+        for (int t = 0; t < j; ++t) d -= sh.M[j][t] * sh.M[j][t];
+        d = sqrtf(fmaxf(d, 1e-12f));
+        float di = 1.0f / d;
+        PF_LANES(ii, NV - j - 1) {
+          int i = j + 1 + ii;
+          float s = sh.M[i][j];
+          for (int t = 0; t < j; ++t) s -= sh.M[i][t] * sh.M[j][t];
+          sh.M[i][j] = s * di;
+        }
+        PF_ONE { sh.dinv[j] = di; }
+        PF_SYNC();
+      }
     }
     PF_STAMP(sh, 4);
     // ---- contact candidates: every collision sphere against the terrain
@@ -598,7 +633,7 @@ struct PfKernel {
     }
     PF_SYNC();
     PF_STAMP(sh, 6);
-    solve_rows(sh, 3 * ncon, true);
+    solve_rows(sh, 3 * ncon, true, Lr, dv);
     PF_SYNC();
     PF_STAMP(sh, 7);
     // ---- free velocity
@@ -629,7 +664,7 @@ struct PfKernel {
       sh.lam[rr] = 0.0f;
     }
     PF_SYNC();
-    solve_rows_range(sh, CROWS, nlim);
+    solve_rows_range(sh, CROWS, nlim, Lr, dv);
     PF_SYNC();
     PF_STAMP(sh, 8);
     // ---- per-contact 3x3 Delassus blocks
@@ -806,7 +841,7 @@ struct PfKernel {
   }
 
   // W[row] <- M^-1 J[row]^T by forward/back substitution on the in-place Cholesky factor; Ainv = 1/(J.W)
-  PF_DEV void solve_one(Shared& sh, int rr) {
+  PF_DEV void solve_one(Shared& sh, int rr, const float (&Lr)[NLT], const float (&dv)[NDV]) {
     float w[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) w[i] = sh.W[rr][i];
@@ -814,26 +849,26 @@ struct PfKernel {
     for (int i = 0; i < NV; ++i) {
       float s = w[i];
 #pragma unroll
-      for (int t = 0; t < i; ++t) s -= sh.M[i][t] * w[t];
-      w[i] = s * sh.dinv[i];
+      for (int t = 0; t < i; ++t) s -= (CHOLR ? Lr[CHOLR ? lt(i, t) : 0] : sh.M[i][t]) * w[t];
+      w[i] = s * (CHOLR ? dv[CHOLR ? i : 0] : sh.dinv[i]);
     }
 #pragma unroll
     for (int i = NV - 1; i >= 0; --i) {
       float s = w[i];
 #pragma unroll
-      for (int t = i + 1; t < NV; ++t) s -= sh.M[t][i] * w[t];
-      w[i] = s * sh.dinv[i];
+      for (int t = i + 1; t < NV; ++t) s -= (CHOLR ? Lr[CHOLR ? lt(t, i) : 0] : sh.M[t][i]) * w[t];
+      w[i] = s * (CHOLR ? dv[CHOLR ? i : 0] : sh.dinv[i]);
     }
     float a = 0.0f;
 #pragma unroll
     for (int t = 0; t < NV; ++t) { a += sh.J[rr][t] * w[t]; sh.W[rr][t] = w[t]; }
     sh.rAinv[rr] = 1.0f / fmaxf(a, 1e-9f);
   }
-  PF_DEV void solve_rows(Shared& sh, int nrows, bool with_free) {
-    PF_LANES(x, nrows + (with_free ? 1 : 0)) { solve_one(sh, x < nrows ? x : RFREE); }
+  PF_DEV void solve_rows(Shared& sh, int nrows, bool with_free, const float (&Lr)[NLT], const float (&dv)[NDV]) {
+    PF_LANES(x, nrows + (with_free ? 1 : 0)) { solve_one(sh, x < nrows ? x : RFREE, Lr, dv); }
   }
-  PF_DEV void solve_rows_range(Shared& sh, int first, int n) {
-    PF_LANES(x, n) { solve_one(sh, first + x); }
+  PF_DEV void solve_rows_range(Shared& sh, int first, int n, const float (&Lr)[NLT], const float (&dv)[NDV]) {
+    PF_LANES(x, n) { solve_one(sh, first + x, Lr, dv); }
   }
 
   // ------------------------------------------------------------------ observations (:320-382, :189-192)
