@@ -49,7 +49,7 @@ constexpr int PF_GEMM_LDS_S = PF_GEMM_BK + 4;      // LDS row stride (floats): 1
 // The kernel body: block `bid` of `nblk` blocks working on problem `g` (so one launch can carry two problems, see
 // pf_gemm_kernel2); As / Bs are the workgroup's LDS tiles (BM x LDS_S and BN x LDS_S floats).
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool VEC>
-__device__ __forceinline__ void pf_gemm_body(const GemmArgs& g, const int bid, const int nblk, float* __restrict__ As, float* __restrict__ Bs) {
+__device__ __forceinline__ void pf_gemm_body(const GemmArgs& g, const int bid, const int nblk, float* As, float* Bs) {
   constexpr int BK = PF_GEMM_BK;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int LDS_S = PF_GEMM_LDS_S;
@@ -147,6 +147,10 @@ __device__ __forceinline__ void pf_gemm_body(const GemmArgs& g, const int bid, c
   if (t >= tmax) return;
   fetch(cur, cur.k_begin);
   const int arow = wr * (BM / 2) + (lane & 31), bcol = wc * (BN / 2) + (lane & 31), kh = lane >> 5;
+  // dwordx4 write-out possible: rows of C (and of H, and the bias) 16-byte aligned, width a multiple of 4
+  bool cvec = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && ((((size_t)g.C) & 15) == 0) && (!COLSUM || (g.M & 3) == 0);
+  if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) cvec = cvec && ((((size_t)g.bias) & 15) == 0);
+  if (EPI == GEMM_EPI_MUL_DELU) cvec = cvec && ((g.ldh & 3) == 0) && ((((size_t)g.H) & 15) == 0);
 
   while (true) {
     // ---- v_mfma_f32_32x32x2_f32: wave tile = TM x TN tiles of 32x32
@@ -193,6 +197,41 @@ __device__ __forceinline__ void pf_gemm_body(const GemmArgs& g, const int bid, c
     if (more) fetch(nxt, nxt.k_begin);
 
     if (COLSUM && cur.bx == 0 && tid < BM && cur.m0 + tid < g.M) cur.C[(size_t)g.M * g.ldc + cur.m0 + tid] = csum;
+    bool done = false;
+    if constexpr (BM == 64 && BN == 64) {
+      if (cvec) {      // uniform
+        // 64x64 tiles, 16-byte aligned C rows: transpose the accumulators through LDS (the operand tiles are dead) so a lane
+        // writes 4 x dwordx4 of one row instead of 16 dwords in 16 rows -- the write-out is store-issue bound.
+        float* Cs = As;                      // As and Bs are contiguous: (64 + 64) * 36 floats >= 64 * 64
+        __syncthreads();                     // the last slice's fragment reads are done in every wave
+#pragma unroll
+        for (int r = 0; r < 16; ++r)         // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+          Cs[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + wc * 32 + (lane & 31)] = acc[0][0][r];
+        __syncthreads();
+        const int c4 = tid & 15, r0 = tid >> 4;
+        const int col = cur.n0 + 4 * c4;
+        if (col < g.N) {                     // N % 4 == 0: the whole quad is inside
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) b4 = *reinterpret_cast<const float4*>(g.bias + col);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int rl = r0 + 16 * p, row = cur.m0 + rl;
+            if (row >= g.M) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[rl * 64 + 4 * c4]);
+            if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+            if (EPI == GEMM_EPI_BIAS_ELU) { v.x = pf_elu(v.x); v.y = pf_elu(v.y); v.z = pf_elu(v.z); v.w = pf_elu(v.w); }
+            if (EPI == GEMM_EPI_MUL_DELU) {
+              const float4 h = *reinterpret_cast<const float4*>(g.H + (size_t)row * g.ldh + col);
+              v.x *= (h.x > 0.0f ? 1.0f : h.x + 1.0f); v.y *= (h.y > 0.0f ? 1.0f : h.y + 1.0f);
+              v.z *= (h.z > 0.0f ? 1.0f : h.z + 1.0f); v.w *= (h.w > 0.0f ? 1.0f : h.w + 1.0f);
+            }
+            *reinterpret_cast<float4*>(cur.C + (size_t)row * g.ldc + col) = v;
+          }
+        }
+        done = true;
+      }
+    }
+    if (!done) {
     // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -212,6 +251,7 @@ __device__ __forceinline__ void pf_gemm_body(const GemmArgs& g, const int bid, c
           cur.C[(size_t)row * g.ldc + col] = v;
         }
       }
+    }
     if (!more) break;
     cur = nxt; t = tn;
   }
@@ -220,8 +260,8 @@ __device__ __forceinline__ void pf_gemm_body(const GemmArgs& g, const int bid, c
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false, bool VEC = true>
 __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[BM * PF_GEMM_LDS_S];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * PF_GEMM_LDS_S];
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * PF_GEMM_LDS_S];     // A tile then B tile, contiguous
+  float* As = smem; float* Bs = smem + BM * PF_GEMM_LDS_S;
   pf_gemm_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC>(g, (int)blockIdx.x, (int)gridDim.x, As, Bs);
 }
 // Two independent problems of the same arrangement in one launch (the actor's and the critic's layer i): blocks
@@ -229,8 +269,8 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
 // without cross-stream events.  nb0 is a multiple of 8 so the XCD of a block is the same function of its local id.
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool VEC0, bool VEC1>
 __global__ __launch_bounds__(256) void pf_gemm_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
-  __shared__ __attribute__((aligned(16))) float As[BM * PF_GEMM_LDS_S];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * PF_GEMM_LDS_S];
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * PF_GEMM_LDS_S];     // A tile then B tile, contiguous
+  float* As = smem; float* Bs = smem + BM * PF_GEMM_LDS_S;
   if ((int)blockIdx.x < nb0) pf_gemm_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC0>(g0, (int)blockIdx.x, nb0, As, Bs);
   else pf_gemm_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC1>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, As, Bs);
 }
