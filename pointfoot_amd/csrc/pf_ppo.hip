@@ -575,45 +575,59 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
   }
   val += __shfl_xor(val, 1, 64); val += __shfl_xor(val, 2, 64); val += __shfl_xor(val, 4, 64);
   val += bc[0];
-  // ---- loss (k_loss formulas); lane8 == 0 of each row does the per-sample scalar work
-  float dstd[16], kl = 0.0f, vl = 0.0f, sl = 0.0f, en = 0.0f;
+  // ---- loss (k_loss formulas): lane j of a row's 8-lane group does action dimensions j and j + 8 (the divisions and
+  //      logs are the bulk of the instructions), the per-sample sums come back by a 3-step shuffle inside the group
+  float dstd_own[2] = {0.0f, 0.0f}, kl = 0.0f, vl = 0.0f, sl = 0.0f, en = 0.0f;
+  {
+    const int i = rv ? row : 0;
+    float lp = 0.0f, kls = 0.0f, ens = 0.0f, dmu_own[2] = {0.0f, 0.0f}, dsg_own[2] = {0.0f, 0.0f};
 #pragma unroll
-  for (int k = 0; k < 16; ++k) dstd[k] = 0.0f;
-  if (rv && lane8 == 0) {
-    const int i = row;
-    float lp = 0.0f, kls = 0.0f, ens = 0.0f;
-    float dmu[16], dsg[16];
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = lane8 + 8 * kk;
+      if (rv && k < A) {
+        float m = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) if (k < A) {
-      float m = mu[k], sg = stdp[k], a = act[(size_t)i * A + k];
-      float d = a - m;
-      lp += -0.5f * (d * d) / (sg * sg) - logf(sg) - 0.91893853320467274178f;
-      dmu[k] = d / (sg * sg);
-      dsg[k] = (d * d) / (sg * sg * sg) - 1.0f / sg;
-      float om = old_mu[(size_t)i * A + k], os = old_sigma[(size_t)i * A + k];
-      kls += logf(sg / os + 1e-5f) + (os * os + (om - m) * (om - m)) / (2.0f * sg * sg) - 0.5f;
-      ens += 0.5f + 0.91893853320467274178f + logf(sg);
+        for (int o = 0; o < 16; ++o) if (o == k) m = mu[o];       // register select (mu[] is indexed by constants only)
+        const float sg = stdp[k], a = act[(size_t)i * A + k];
+        const float d = a - m;
+        lp += -0.5f * (d * d) / (sg * sg) - logf(sg) - 0.91893853320467274178f;
+        dmu_own[kk] = d / (sg * sg);
+        dsg_own[kk] = (d * d) / (sg * sg * sg) - 1.0f / sg;
+        const float om = old_mu[(size_t)i * A + k], os = old_sigma[(size_t)i * A + k];
+        kls += logf(sg / os + 1e-5f) + (os * os + (om - m) * (om - m)) / (2.0f * sg * sg) - 0.5f;
+        ens += 0.5f + 0.91893853320467274178f + logf(sg);
+      }
     }
-    float ad = adv[i];
-    float ratio = expf(lp - old_logp[i]);
-    float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
-    float g_lp = (s1 >= s2) ? (-ad * ratio) * invB : 0.0f;
-    sl = fmaxf(s1, s2);
-    float v = val, r = ret[i], gv;
-    if (clipped_value) {
-      float ov = old_val[i];
-      float vc = ov + fminf(fmaxf(v - ov, -clip), clip);
-      float e1 = (v - r) * (v - r), e2 = (vc - r) * (vc - r);
-      bool inside = fabsf(v - ov) < clip;
-      gv = (e1 >= e2 || inside) ? 2.0f * (v - r) : 0.0f;
-      vl = fmaxf(e1, e2);
-    } else { gv = 2.0f * (v - r); vl = (r - v) * (r - v); }
-    sD[lr * (A + 1) + A] = vcoef * gv * invB;
+    lp += __shfl_xor(lp, 1, 64); lp += __shfl_xor(lp, 2, 64); lp += __shfl_xor(lp, 4, 64);
+    kls += __shfl_xor(kls, 1, 64); kls += __shfl_xor(kls, 2, 64); kls += __shfl_xor(kls, 4, 64);
+    ens += __shfl_xor(ens, 1, 64); ens += __shfl_xor(ens, 2, 64); ens += __shfl_xor(ens, 4, 64);
+    float g_lp = 0.0f;
+    if (rv) {
+      const float ad = adv[i];
+      const float ratio = expf(lp - old_logp[i]);
+      const float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+      g_lp = (s1 >= s2) ? (-ad * ratio) * invB : 0.0f;
+      if (lane8 == 0) {
+        sl = fmaxf(s1, s2);
+        const float v = val, r = ret[i];
+        float gv;
+        if (clipped_value) {
+          const float ov = old_val[i];
+          const float vc = ov + fminf(fmaxf(v - ov, -clip), clip);
+          const float e1 = (v - r) * (v - r), e2 = (vc - r) * (vc - r);
+          const bool inside = fabsf(v - ov) < clip;
+          gv = (e1 >= e2 || inside) ? 2.0f * (v - r) : 0.0f;
+          vl = fmaxf(e1, e2);
+        } else { gv = 2.0f * (v - r); vl = (r - v) * (r - v); }
+        sD[lr * (A + 1) + A] = vcoef * gv * invB;
+        kl = kls; en = ens;
+      }
+    } else if (lane8 == 0) sD[lr * (A + 1) + A] = 0.0f;            // rows past the batch contribute nothing
 #pragma unroll
-    for (int k = 0; k < 16; ++k) if (k < A) { sD[lr * (A + 1) + k] = g_lp * dmu[k]; dstd[k] = g_lp * dsg[k]; }
-    kl = kls; en = ens;
-  } else if (lane8 == 0) {
-    for (int k = 0; k <= A; ++k) sD[lr * (A + 1) + k] = 0.0f;      // rows past the batch contribute nothing
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = lane8 + 8 * kk;
+      if (k < A) { sD[lr * (A + 1) + k] = g_lp * dmu_own[kk]; dstd_own[kk] = g_lp * dsg_own[kk]; }
+    }
   }
   // block partials: wave sums (fixed shuffle tree) -> LDS -> thread 0 adds the four waves in order
   {
@@ -623,8 +637,14 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
       return v;
     };
+    // dL/dstd[k]: lanes with lane8 == k (mod 8) of the wave's 8 rows -> shuffle over the row bits only
 #pragma unroll
-    for (int k = 0; k < 16; ++k) if (k < A) { float t = wsum(dstd[k]); if ((threadIdx.x & 63) == 0) sP[w * (A + 4) + k] = t; }
+    for (int kk = 0; kk < 2; ++kk) {
+      float t = dstd_own[kk];
+      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+      const int k = lane8 + 8 * kk;
+      if ((threadIdx.x & 63) < 8 && k < A) sP[w * (A + 4) + k] = t;
+    }
     float t;
     t = wsum(kl); if ((threadIdx.x & 63) == 0) sP[w * (A + 4) + A] = t;
     t = wsum(vl); if ((threadIdx.x & 63) == 0) sP[w * (A + 4) + A + 1] = t;
