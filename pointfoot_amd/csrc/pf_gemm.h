@@ -316,11 +316,11 @@ static inline void pf_gemm_launch2(const GemmArgs& g0_in, int splits0, const Gem
   else hipLaunchKernelGGL((pf_gemm_kernel2<64, 64, A_KC, B_KC, EPI, COLSUM, HAS_KC ? false : true, HAS_KC ? false : true>), grid, block, 0, s, g0, g1, nb0);
 }
 
-// Tile choice from a small cost model calibrated on MI355X (tools/gemm_bench.py): the main loop runs at the matrix
-// pipe's rate (64 cycles per v_mfma_f32_32x32x2_f32 at the ~1.57 GHz the chip sustains on random fp32 data), every block
-// pays a prologue/epilogue cost that grows with its tile (first global->LDS fill, C-tile write with bias/ELU), and the
-// grid runs in ceil(blocks / 256 CUs) rounds.  Returns the modelled time in cycles; `tile_out` = 0: 128x128, 1: 128x64,
-// 2: 64x64.
+// Tile choice from a small cost model fitted to measurements on MI355X (tools/gemm_bench.py): a k-slice costs the tile's
+// MFMA time (64 cycles per v_mfma_f32_32x32x2_f32) divided by a per-tile efficiency, every block pays a prologue/epilogue
+// cost that grows with its tile (first global->LDS fill, C-tile write with bias/ELU), and the grid runs in
+// ceil(blocks / 256 CUs) rounds.  Only the ranking matters (every PPO shape ranks 64x64 first; 4096^3 ranks 128x64 first,
+// as measured).  Returns the modelled time in cycles; `tile_out` = 0: 128x128, 1: 128x64, 2: 64x64.
 static inline float pf_tile_cost(int M, int N, int K, int splits, int t) {
   const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
   const float cyc[3] = {4096.0f, 2048.0f / 0.95f, 1024.0f / 0.90f}, ovh[3] = {30000.0f, 11000.0f, 4200.0f};
