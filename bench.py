@@ -30,7 +30,7 @@ STEP_BYTES_PER_ENV = 2072      # algorithmic bytes per env-ste
 PPO_MFLOP_PER_ENV_STEP = 13.4  # 0.84 rollout + 12.5 update
 # HBM bytes per step-kernel launch from rocprofv3 PMC passes (profiles/r1_step_kernel_hbm_pmc.md; N=4096 rough):
 # FETCH_SIZE 8104 KB (x2: gfx950 half-count correction) + WRITE_SIZE 24345 KB (15 MB of it scratch write-back)
-STEP_TRAFFIC_BYTES_N4096_ROUGH = 2 * 8104.4 * 1024 + 24345.1 * 1024
+STEP_TRAFFIC_BYTES_N4096_ROUGH = 2 * 3878.0 * 1024 + 7545.0 * 1024     # profiles/r1_step_kernel_hbm_pmc.md (FETCH_SIZE x2 upper bound + WRITE_SIZE)
 
 
 def parse():
