@@ -46,6 +46,13 @@ template <int CTRL>
 PF_DEV float pf_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// sum over a 32-lane group (two DPP rows): row sums, then the neighbouring row's total through ds_swizzle (lane ^ 16);
+// a + b == b + a bit for bit, so both rows end with the same value
+PF_DEV float pf_row16_sum(float v);
+PF_DEV float pf_group32_sum(float v) {
+  v = pf_row16_sum(v);
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
 PF_DEV float pf_row16_sum(float v) {
   v += pf_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
   v += pf_dpp<0x4E>(v);     // quad_perm [2,3,0,1]

@@ -682,13 +682,14 @@ struct PfKernel {
     // updates need no barrier; J and W rows are LDS broadcast reads.
     const float mu = 0.5f * (S[LC::friction] + c.terrain_friction);
 #if !defined(PF_HOST_EMU)
-    if constexpr (NV <= 16) {
-      // GPU form for <= 16 velocity components: lane t of each 16-lane DPP row owns v[t] and column t of every J / W row
+    if constexpr (NV <= 32) {
+      // GPU form: lane t of each 16-lane DPP row (NV <= 16) or 32-lane group (NV <= 32) owns v[t] and column t of every J / W row
       // (loop-invariant, in registers with the impulses); a row's J.v is one multiply + a 4-step DPP butterfly whose result
       // is bit-identical in all lanes (IEEE add is commutative and every lane walks the same tree), so the uniform impulse
       // math stays consistent.  No LDS traffic inside the sweep except the broadcast reads of rb / 1/A / the Delassus block.
-      const int tl = PF_LANE_ID & 15;
+      const int tl = PF_LANE_ID & (NV <= 16 ? 15 : 31);
       const bool tv = tl < NV;
+      auto rsum = [](float x) { if constexpr (NV <= 16) return pf_row16_sum(x); else return pf_group32_sum(x); };
       float v = tv ? sh.vel[tl] : 0.0f;
       float jc[MAXC][3], wc[MAXC][3], lc[MAXC][3], jl[ND], wl[ND], ll[ND];
 #pragma unroll
@@ -712,7 +713,7 @@ struct PfKernel {
         for (int ci = 0; ci < MAXC; ++ci) {
           if (ci < ncon) {
             const int r0 = 3 * ci;
-            const float u0 = pf_row16_sum(jc[ci][0] * v), u1 = pf_row16_sum(jc[ci][1] * v), u2 = pf_row16_sum(jc[ci][2] * v);
+            const float u0 = rsum(jc[ci][0] * v), u1 = rsum(jc[ci][1] * v), u2 = rsum(jc[ci][2] * v);
             const float l0 = lc[ci][0], l1o = lc[ci][1], l2o = lc[ci][2];
             const float ln = fmaxf(0.0f, l0 + (sh.rb[r0] - u0) * sh.rAinv[r0]);
             const float d0 = ln - l0;
@@ -732,7 +733,7 @@ struct PfKernel {
         for (int li = 0; li < ND; ++li) {
           if (li < nlim) {
             const int rr = CROWS + li;
-            const float u = pf_row16_sum(jl[li] * v);
+            const float u = rsum(jl[li] * v);
             const float lo = ll[li];
             const float ln = fmaxf(0.0f, lo + (sh.rb[rr] - u) * sh.rAinv[rr]);
             v += wl[li] * (ln - lo);
