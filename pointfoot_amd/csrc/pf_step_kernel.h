@@ -146,6 +146,13 @@ struct PfKernel {
   // and factorises redundantly with static indices: no LDS round trips, no barriers), and the substitutions read it there
   static constexpr bool CHOLR = NV <= 12;
 #endif
+#if defined(PF_HOST_EMU)
+  static constexpr bool CHOLL = false;
+#else
+  // wider systems, one robot per wavefront: lane i keeps row i of the factor in registers and the pivot row reaches the
+  // other lanes through v_readlane (wave-uniform SGPR operands) -- no LDS traffic or barriers during the factorisation
+  static constexpr bool CHOLL = !CHOLR && RPW == 1 && NV <= 32;
+#endif
   static constexpr int NLT = CHOLR ? NV * (NV + 1) / 2 : 1;
   static constexpr int NDV = CHOLR ? NV : 1;
   static constexpr int lt(int i, int t) { return i * (i + 1) / 2 + t; }
@@ -546,6 +553,34 @@ struct PfKernel {
           Lr[lt(i, j)] = sacc * di;
         }
       }
+    } else if constexpr (CHOLL) {
+#if !defined(PF_HOST_EMU)
+      const int li = PF_LANE_ID;
+      float r[NV];
+#pragma unroll
+      for (int t = 0; t < NV; ++t) r[t] = (li < NV && t <= li) ? sh.M[li < NV ? li : 0][t] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        float pj[NV];
+#pragma unroll
+        for (int t = 0; t < j; ++t) pj[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[t]), j));
+        float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[j]), j));
+#pragma unroll
+        for (int t = 0; t < j; ++t) d -= pj[t] * pj[t];
+        d = sqrtf(fmaxf(d, 1e-12f));
+        const float di = 1.0f / d;
+        float sacc = r[j];
+#pragma unroll
+        for (int t = 0; t < j; ++t) sacc -= r[t] * pj[t];
+        r[j] = li > j ? sacc * di : r[j];
+        if (li == j) sh.dinv[j] = di;
+      }
+      if (li < NV) {
+#pragma unroll
+        for (int t = 0; t < NV; ++t) if (t < li) sh.M[li][t] = r[t];
+      }
+      PF_SYNC();
+#endif
     } else {
       // in place in LDS, one column per phase
       for (int j = 0; j < NV; ++j) {

@@ -1,6 +1,6 @@
 """Diagnostic: where one policy step of pf_step_kernel spends its cycles (s_memtime stamps, lane 0 of every wave).
 Builds a separate libpointfoot_hip_stamps.so with -DPF_STAMPS (the product library contains no stamp), runs
-pointfoot_rough N=4096 and prints the mean cycles per phase.  Read SHARES, not absolute times."""
+`python tools/step_stamps.py [N] [task]` (default pointfoot_rough, N=4096) and prints the mean cycles per phase.  Read SHARES, not absolute times."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,8 +14,9 @@ import torch
 from pointfoot_amd.envs import task_registry
 from pointfoot_amd.utils import get_args
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-args = get_args(["--task", "pointfoot_rough", "--headless", "--num_envs", str(N)])
-env, _ = task_registry.make_env("pointfoot_rough", args=args)
+task = sys.argv[2] if len(sys.argv) > 2 else "pointfoot_rough"
+args = get_args(["--task", task, "--headless", "--num_envs", str(N)])
+env, _ = task_registry.make_env(task, args=args)
 env.reset()
 lib = _abi.load()
 stamps = torch.zeros(N, 16, dtype=torch.int32, device="cuda:0")
@@ -25,7 +26,7 @@ g = torch.Generator(device="cuda:0").manual_seed(0)
 acc = torch.zeros(16, dtype=torch.float64, device="cuda:0")
 K = 40
 for i in range(K + 10):
-    env.step(torch.randn(N, 6, device="cuda:0", generator=g) * 0.5)
+    env.step(torch.randn(N, env.num_actions, device="cuda:0", generator=g) * 0.5)
     if i >= 10:
         acc += stamps.double().mean(0)
 torch.cuda.synchronize()
