@@ -164,3 +164,40 @@ def test_gemm_shapes_against_torch():
         common._abi.check(alg._lib.ppo_act_inference(alg._h, x.data_ptr(), n, out.data_ptr(), alg._stream()))
         with torch.no_grad():
             torch.testing.assert_close(out, ref.actor(x), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["fwd_bias_elu", "bwd_x_delu", "bwd_w_splitk_colsum"])
+def test_gemm_kernel_family_on_ragged_shapes(mode):
+    """The fp32 MFMA GEMM family (pf_gemm.h) through its test hook, every tile variant, on shapes that exercise the edges:
+    rows / columns / reduction lengths that are not multiples of the tile, of 4 (scalar loads and write-out) or of the
+    k-slice, single-row problems, and split-K with a ragged last split.  Reference: torch fp32 matmul."""
+    lib = common._abi.load()
+    lib.pf_gemm_test.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
+    dev = "cuda:0"
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    R = lambda *s: torch.rand(*s, device=dev, generator=gen) * 2 - 1
+    shapes = [(1, 5, 3), (64, 64, 32), (130, 70, 45), (257, 96, 100), (200, 132, 260), (96, 28, 1000), (33, 512, 27)]
+    for (M, N, K) in shapes:
+        for tile in (0, 1, 2, -1):
+            for splits in ((1, 7, 64) if mode == 2 else (0,)):
+                if mode == 0: A, B = R(M, K), R(N, K)
+                elif mode == 1: A, B = R(M, K), R(K, N)
+                else: A, B = R(K, M), R(K, N)
+                bias, H = R(N), R(M, N)
+                out = torch.full((M * N + M,), float("nan"), device=dev)
+                ws = torch.zeros(max(splits, 1) * (M * N + M) + 64, device=dev)
+                rc = lib.pf_gemm_test(mode, M, N, K, A.data_ptr(), B.data_ptr(), out.data_ptr(), bias.data_ptr(), H.data_ptr(),
+                                      ws.data_ptr(), max(splits, 1), tile, stream)
+                assert rc == 0, lib.pf_last_error()
+                torch.cuda.synchronize()
+                if mode == 0: ref = torch.nn.functional.elu(A @ B.t() + bias)
+                elif mode == 1: ref = (A @ B) * torch.where(H > 0, torch.ones_like(H), H + 1)
+                else: ref = A.t() @ B
+                got = out[:M * N].view(M, N)
+                tol = 2e-5 * max(1.0, float(ref.abs().max())) * max(1.0, K / 64) ** 0.5
+                assert torch.isfinite(got).all(), (mode, M, N, K, tile, splits)
+                assert float((got - ref).abs().max()) <= tol, (mode, M, N, K, tile, splits, float((got - ref).abs().max()), tol)
+                if mode == 2:
+                    cs = A.sum(0)
+                    assert float((out[M * N:] - cs).abs().max()) <= 2e-5 * max(1.0, float(cs.abs().max())) * max(1.0, K / 64) ** 0.5
