@@ -27,18 +27,27 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // touches its own record, so no inter-workgroup ordering is needed.
 // model / cfg are separate __restrict__ const kernel arguments so the compiler can prove they are invariant and
 // read them with scalar loads (s_load) into SGPRs instead of holding hundreds of config values in VGPRs.
-template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1>
-__global__ __launch_bounds__(64, WAVES) void pf_step_kernel(const PfModel* __restrict__ model, const PfConfig* __restrict__ cfg, PfStepArgs g) {
+// WPB wavefronts per workgroup (each with RPW robots) share one read-only block (model, actuator parameters) in LDS; the
+// rest of the LDS is per robot.  WAVES = waves per SIMD the register budget is sized for.  LDS comes as dynamic shared
+// memory (the quadruped workgroup of 8 robots needs ~145 KB, above the static limit).
+template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB, WPB == 1 ? WAVES : 1) void pf_step_kernel(const PfModel* __restrict__ model, const PfConfig* __restrict__ cfg, PfStepArgs g) {
   using K = PfKernel<NB, ND, NF, KIND, KS, RPW>;
-  __shared__ typename K::Shared sh[RPW];
+  extern __shared__ __attribute__((aligned(16))) unsigned char pf_lds[];
+  typename K::SharedRO& ro = *reinterpret_cast<typename K::SharedRO*>(pf_lds);
+  typename K::Shared* sh = reinterpret_cast<typename K::Shared*>(pf_lds + ((sizeof(typename K::SharedRO) + 15) & ~size_t(15)));
   g.model = model; g.cfg = cfg;
   // the slot the *next* launch accumulates into is cleared here, so a rollout needs no memset between steps
   if (blockIdx.x == 0 && g.stats_next && threadIdx.x < PF_STATS_FLOATS) g.stats_next[threadIdx.x] = 0.0f;
-  // RPW robots per wavefront: each group of 64 / RPW lanes runs the phase program on its own robot and its own LDS block
-  const int part = (int)threadIdx.x / (64 / RPW);
-  const int env = (int)blockIdx.x * RPW + part;
+  // each group of 64 / RPW lanes runs the phase program on its own robot and its own LDS block
+  const int slot = (int)threadIdx.x / (64 / RPW);            // robot slot inside the workgroup
+  const int env = (int)blockIdx.x * (RPW * WPB) + slot;
   if (env >= cfg->num_envs) return;
-  K::run(sh[part], g, env);
+  K::run(sh[slot], ro, g, env);
+}
+template <class K, int RPW, int WPB>
+static constexpr size_t pf_lds_bytes() {
+  return ((sizeof(typename K::SharedRO) + 15) & ~size_t(15)) + sizeof(typename K::Shared) * RPW * WPB;
 }
 
 struct PfEnv {
@@ -195,14 +204,23 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   static const int rpw = [] { const char* v = getenv("PF_STEP_RPW"); return v ? atoi(v) : 2; }();
   static const int variant = [] { const char* v = getenv("PF_STEP_WAVES"); return v ? atoi(v) : 4; }();
   const int N = e->cfg.num_envs;
-  dim3 grid(N), block(64);
-  // (two robots per wave were also tried for the quadruped instance and for four PointFoot robots per wave: no gain --
-  // 0.843 vs 0.834 ms and 0.185 vs 0.172 ms -- LDS per robot caps the resident waves there)
-  if (e->instance == 1) hipLaunchKernelGGL((pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>), grid, block, 0, s, e->d_model, e->d_cfg, g);
-  else if (rpw == 2) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2>), dim3((N + 1) / 2), block, 0, s, e->d_model, e->d_cfg, g);
-  else if (variant == 4) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 4>), grid, block, 0, s, e->d_model, e->d_cfg, g);
-  else if (variant == 3) hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 3>), grid, block, 0, s, e->d_model, e->d_cfg, g);
-  else hipLaunchKernelGGL((pf_step_kernel<9, 6, 2, 2>), grid, block, 0, s, e->d_model, e->d_cfg, g);
+  // (two robots per wave were also tried for the quadruped instance and four PointFoot robots per wave: no gain --
+  // 0.843 vs 0.834 ms and 0.185 vs 0.172 ms at the time)
+  auto launch = [&](auto kern, size_t lds, int robots_per_block, int threads) {
+    static bool raised = false;          // one kernel per env handle in practice; raising the limit again is harmless
+    if (lds > 64 * 1024 && !raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
+    hipLaunchKernelGGL(kern, dim3((N + robots_per_block - 1) / robots_per_block), dim3(threads), lds, s, e->d_model, e->d_cfg, g);
+  };
+  using KLR = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1>;
+  using KP1 = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 1>;
+  using KP2 = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 2>;
+  static const int wpb_lr = [] { const char* v = getenv("PF_STEP_WPB_LR"); return v ? atoi(v) : 8; }();
+  if (e->instance == 1 && wpb_lr == 8) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8>, pf_lds_bytes<KLR, 1, 8>(), 8, 512);
+  else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 1>, pf_lds_bytes<KLR, 1, 1>(), 1, 64);
+  else if (rpw == 2) launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 1>, pf_lds_bytes<KP2, 2, 1>(), 2, 64);
+  else if (variant == 4) launch(pf_step_kernel<9, 6, 2, 4, PF_KIND_POINTFOOT, PF_KSPH, 1, 1>, pf_lds_bytes<KP1, 1, 1>(), 1, 64);
+  else if (variant == 3) launch(pf_step_kernel<9, 6, 2, 3, PF_KIND_POINTFOOT, PF_KSPH, 1, 1>, pf_lds_bytes<KP1, 1, 1>(), 1, 64);
+  else launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 1, 1>, pf_lds_bytes<KP1, 1, 1>(), 1, 64);
   PF_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -31,7 +31,16 @@
 // per wavefront, one per half -- uniform sections and loops over <= 32 items then cost one instruction for two robots.
 #define PF_LANE_ID ((int)threadIdx.x & (PF_W - 1))
 #define PF_LANES(i, n) for (int i = PF_LANE_ID; i < (n); i += PF_W)
-#define PF_SYNC() __syncthreads()
+// One wavefront (or half of one) per robot, possibly several wavefronts per workgroup that share only read-only data: a
+// "barrier" has to order just the wave's own LDS traffic.  The hardware executes a wave's LDS instructions in order, which
+// leaves the compiler as the only thing to restrain -- a wavefront-scope fence pair around a wave barrier.  Robots in
+// one workgroup may therefore diverge (a reset takes extra phases) without any workgroup barrier to mismatch.
+PF_DEV void pf_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#define PF_SYNC() pf_wave_sync()
 #define PF_ONE if (PF_LANE_ID == 0)
 template <int W>
 PF_DEV float pf_wave_sum(float v) {

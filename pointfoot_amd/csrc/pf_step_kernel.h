@@ -200,14 +200,17 @@ struct PfKernel {
     int nchain, chain_len[PF_MAX_CHAINS], chain[PF_MAX_CHAINS][PF_MAX_CHAIN_DEPTH], rot_ident[NB];
   };
 
-  struct Shared {
+  // read-only per launch, identical for every robot: one copy per workgroup, shared by all its robots
+  struct SharedRO {
     ModelS mdl;
+    float act[LR ? PF_ACT_PARAMS : 1];        // actuator-net parameters (LeggedRobot)
+  };
+  struct Shared {
 #if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
     unsigned long long stamp_last;
     unsigned stamp_acc[PF_NSTAMP];
 #endif
     float rec[REC_MAX];
-    float act[LR ? PF_ACT_PARAMS : 1];        // actuator-net parameters (LeggedRobot)
     float gates[LR ? ND * 32 : 1];            // LSTM gate pre-activations
     float Rw[NB][9], r[NB][3], ax[NB][3];
     float Sj[NB][6], V[NB][6], A[NB][6];      // {ang, lin@O}
@@ -269,8 +272,8 @@ struct PfKernel {
   // per joint: x = [a*scale + q0 - q, qd] * in_scale -> LSTM(2->8) x 2 layers (state h,c persists, zeroed on reset) ->
   // Linear(8->1) * out_scale.  No torque clip on this branch.  Lanes: (joint, gate row) pairs, then (joint, unit) pairs.
   PF_DEV float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
-  PF_DEV void actuator_torques(Shared& sh, const PfConfig& c) {
-    float* S = sh.rec; const float* P = sh.act;
+  PF_DEV void actuator_torques(Shared& sh, const float* P, const PfConfig& c) {
+    float* S = sh.rec;
     for (int layer = 0; layer < 2; ++layer) {
       PF_LANES(e, ND * 32) {
         int j = e >> 5, g = e & 31;
@@ -1022,9 +1025,11 @@ struct PfKernel {
   }
 
   // ------------------------------------------------------------------ the whole step for env `env`
-  PF_DEV void run(Shared& sh, const PfStepArgs& g, int env) {
+  // Every wavefront stages the workgroup's read-only block itself (same values from every wave: no cross-wave ordering is
+  // needed, so PF_SYNC stays wave-local and robots of one workgroup may diverge freely).
+  PF_DEV void run(Shared& sh, SharedRO& ro, const PfStepArgs& g, int env) {
     const PfModel& gm = *g.model; const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
-    ModelS& ms = sh.mdl;
+    ModelS& ms = ro.mdl;
 #if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
     if (threadIdx.x == 0) { sh.stamp_last = __builtin_amdgcn_s_memtime(); for (int t = 0; t < PF_NSTAMP; ++t) sh.stamp_acc[t] = 0; }
 #endif
@@ -1044,7 +1049,7 @@ struct PfKernel {
     PF_LANES(t, PF_MAX_TERM) ms.term_body[t] = gm.term_body[t];
     PF_LANES(t, PF_MAX_PEN) ms.pen_body[t] = gm.pen_body[t];
     PF_ONE { ms.nsph = gm.nsph; ms.n_term = gm.n_term; ms.n_pen = gm.n_pen; }
-    if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { PF_LANES(i, PF_ACT_PARAMS) sh.act[i] = B.d_actuator_params[i]; } }
+    if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { PF_LANES(i, PF_ACT_PARAMS) ro.act[i] = B.d_actuator_params[i]; } }
     const ModelS& m = ms;
     float* S = sh.rec;
     bool need_chains = true;
@@ -1100,7 +1105,7 @@ struct PfKernel {
       for (int sub = 0; sub < c.decimation; ++sub) {     // :180-185
         PF_STAMP(sh, 0);
         bool pd = true;
-        if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { actuator_torques(sh, c); pd = false; } }
+        if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { actuator_torques(sh, ro.act, c); pd = false; } }
         if (pd) torques(sh, c, L, S + LC::dof_pos, 1, LC::dof_vel - LC::dof_pos);
         PF_STAMP(sh, 12);
         bool ext = sub == 0 && S[LC::ext_force + 3] != 0.0f;

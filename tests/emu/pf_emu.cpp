@@ -14,12 +14,12 @@ extern "C" int pfe_step(const PfModel* model, const PfConfig* cfg, const PfLayou
   if (bufs->d_reset_stats && mode != 2) std::memset(bufs->d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS);
   if (cfg->env_kind == PF_KIND_POINTFOOT && model->nb == 9 && model->nd == 6 && model->nfeet == 2) {
     using K = PfKernel<9, 6, 2, PF_KIND_POINTFOOT>;
-    static K::Shared sh;
-    for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, g, env);
+    static K::Shared sh; static K::SharedRO ro;
+    for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, ro, g, env);
   } else if (cfg->env_kind == PF_KIND_LEGGED_ROBOT && model->nb == 17 && model->nd == 12 && model->nfeet == 4) {
     using K = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>;
-    static K::Shared sh;
-    for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, g, env);
+    static K::Shared sh; static K::SharedRO ro;
+    for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, ro, g, env);
   } else return 1;
   return 0;
 }
