@@ -1,9 +1,10 @@
 // pf_simt.h — the small SIMT vocabulary the env-step kernel is written in.
 //
-// One wavefront (64 lanes) owns one robot, or each 32-lane half owns one (PF_W).  The kernel is a *phase program*: lane-strided loops
-// (PF_LANES) that touch only their own items, separated by PF_SYNC(), plus "uniform" sections that
-// every lane executes redundantly (all branches on env state are wave-uniform because a wave holds
-// exactly one env).  Shared data lives in LDS.
+// One wavefront (64 lanes) owns one robot, or each 32-lane half owns one (PF_W).  The kernel is a *phase program*:
+// lane-strided loops (PF_LANES) that touch only their own items, separated by PF_SYNC(), plus "uniform" sections that
+// every lane of a robot executes redundantly (branches on env state are uniform across a robot's lanes; two robots in one
+// wave diverge under the EXEC mask).  Per-robot data lives in LDS; a workgroup may hold several wavefronts, which share
+// only a read-only block, so PF_SYNC() is wave-scope.
 //
 // With -DPF_HOST_EMU (used ONLY by tests/, never by the product library) the same program compiles
 // as plain serial C++: PF_LANES becomes an ordinary loop and barriers vanish.  That build checks
