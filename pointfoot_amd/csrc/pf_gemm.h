@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(GemmArgs g) {
 // [0, nb0) work on g0, the rest on g1.  One grid instead of two streams: the tails of one problem are filled by the other
 // without cross-stream events.  nb0 is a multiple of 8 so the XCD of a block is the same function of its local id.
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool VEC0, bool VEC1>
-__global__ __launch_bounds__(256) void pf_gemm_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
+__global__ __launch_bounds__(256, 6) void pf_gemm_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * PF_GEMM_LDS_S];     // A tile then B tile, contiguous
   float* As = smem; float* Bs = smem + BM * PF_GEMM_LDS_S;
   if ((int)blockIdx.x < nb0) pf_gemm_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC0>(g0, (int)blockIdx.x, nb0, As, Bs);
