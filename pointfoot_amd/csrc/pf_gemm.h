@@ -275,6 +275,113 @@ __global__ __launch_bounds__(256, 6) void pf_gemm_kernel2(GemmArgs g0, GemmArgs 
   else pf_gemm_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC1>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, As, Bs);
 }
 
+// ---- weight-gradient GEMM without LDS staging ("direct fragments").
+// C[M,N] (split-K slab z) = sum_k A[k][m] B[k][n] with A = g[rows, out], B = x[rows, in], both row-major over the reduction
+// index.  The MFMA operand layout of v_mfma_f32_32x32x2_f32 is exactly two rows of such a matrix: lane l supplies
+// A[k = 2 step + (l >> 5)][m0 + (l & 31)] -- 32 consecutive floats per half-wave.  So every wave loads its fragments
+// straight from global memory (L1/L2 absorb the 2x reuse between the four waves of a tile): no LDS writes, no bank
+// conflicts and, above all, NO workgroup barriers in the main loop -- the four waves of a block run free.  Per slice of 32
+// rows a wave issues 32 dword loads (one instruction per fragment; the row advance rides in the scalar offset, so there
+// is no vector address arithmetic) one slice ahead of the 16 MFMAs that consume them.  COLSUM: the column sums of A (bias
+// gradient) fall out of the A fragments a lane already holds.
+__device__ __forceinline__ void pf_gemm_bww_body(const GemmArgs& g, const int bid, const int nblk, float* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, kh = lane >> 5, lc = lane & 31;
+  const int tiles_x = (g.N + 63) / 64, tiles_y = (g.M + 63) / 64;
+  const int nsplit = g.nsplit > 0 ? g.nsplit : 1;
+  const int ntiles = tiles_x * tiles_y * nsplit;
+  const int per_xcd = (ntiles + 7) >> 3, tmax = per_xcd << 3;
+  constexpr unsigned OOB = 0x80000000u;
+  const bool cvec = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && ((((size_t)g.C) & 15) == 0) && ((g.M & 3) == 0);
+  for (int t = bid; t < tmax; t += nblk) {
+    const int lt = (t & 7) * per_xcd + (t >> 3);
+    if (lt >= ntiles) continue;
+    const int bx = lt % tiles_x, rest = lt / tiles_x, by = rest % tiles_y, bz = rest / tiles_y;
+    const int m0 = by * 64, n0 = bx * 64;
+    int k_begin = 0, k_end = g.K;
+    float* C = g.C;
+    if (g.k_per_split > 0) {
+      k_begin = bz * g.k_per_split; k_end = min(g.K, k_begin + g.k_per_split);
+      C += (size_t)bz * ((size_t)g.M * g.ldc + g.M);
+    }
+    // per-lane byte offset of row `kh` inside a 16-row group; columns past the matrix read zeros (out-of-range offset)
+    const int ca = m0 + 32 * wr + lc, cb = n0 + 32 * wc + lc;
+    const unsigned va = ca < g.M ? ((unsigned)kh * (unsigned)g.lda + (unsigned)ca) * 4u : OOB;
+    const unsigned vb = cb < g.N ? ((unsigned)kh * (unsigned)g.ldb + (unsigned)cb) * 4u : OOB;
+    const unsigned sa2 = 2u * (unsigned)g.lda * 4u, sb2 = 2u * (unsigned)g.ldb * 4u;      // two rows per MFMA step
+    // 16 rows (8 MFMA steps) per fetch, double-buffered.  The descriptor of a fetch starts at its first row and ends at
+    // the split's last row, so rows past k_end read zeros in hardware: one code path for whole and ragged groups.
+    float a[2][8], b[2][8];
+    auto fetch = [&](int k0, auto set_c) {
+      constexpr int set = decltype(set_c)::value;
+      const unsigned rows = (unsigned)max(0, min(16, k_end - k0));      // 0: every lane out of range, no memory traffic
+      // (wave-uniform by construction; readfirstlane makes that provable so the loads are not wrapped in waterfall loops)
+      auto uni = [](const float* p) {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (float*)(((unsigned long long)hi << 32) | lo);
+      };
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(uni(g.A + (size_t)k0 * g.lda), 0, __builtin_amdgcn_readfirstlane(rows * (unsigned)g.lda * 4u), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(uni(g.B + (size_t)k0 * g.ldb), 0, __builtin_amdgcn_readfirstlane(rows * (unsigned)g.ldb * 4u), 0x00020000);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        a[set][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(va + s * sa2), 0, 0));
+        b[set][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)(vb + s * sb2), 0, 0));
+      }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float csum = 0.0f;
+    // straight-line body (no branches between a fetch and its use, so the waits count exactly the newer loads in flight):
+    // 32 rows per trip, the group after next always requested -- past k_end it is all zeros and costs nothing
+    fetch(k_begin, std::integral_constant<int, 0>{});
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+      fetch(k0 + 16, std::integral_constant<int, 1>{});
+#pragma unroll
+      for (int s = 0; s < 8; ++s) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s], b[0][s], acc, 0, 0, 0); csum += a[0][s]; }
+      fetch(k0 + 32, std::integral_constant<int, 0>{});
+#pragma unroll
+      for (int s = 0; s < 8; ++s) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][s], b[1][s], acc, 0, 0, 0); csum += a[1][s]; }
+    }
+    // bias gradient: column sums of A over this split's rows (waves that own the tile's A columns, first column tile only)
+    csum += __shfl_xor(csum, 32, 64);
+    if (bx == 0 && wc == 0 && kh == 0 && ca < g.M) C[(size_t)g.M * g.ldc + ca] = csum;
+    // write-out (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    if (cvec) {
+      __syncthreads();                   // previous tile's LDS reads are done (persistent grids)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) smem[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 64 + wc * 32 + lc] = acc[r];
+      __syncthreads();
+      const int c4 = tid & 15, r0 = tid >> 4, col = n0 + 4 * c4;
+      if (col < g.N) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int rl = r0 + 16 * p, row = m0 + rl;
+          if (row < g.M) *reinterpret_cast<float4*>(C + (size_t)row * g.ldc + col) = *reinterpret_cast<const float4*>(&smem[rl * 64 + 4 * c4]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < g.M && cb < g.N) C[(size_t)row * g.ldc + cb] = acc[r];
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256, 6) void pf_gemm_bww_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[64 * 64];
+  pf_gemm_bww_body(g, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+__global__ __launch_bounds__(256, 6) void pf_gemm_bww_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
+  __shared__ __attribute__((aligned(16))) float smem[64 * 64];
+  if ((int)blockIdx.x < nb0) pf_gemm_bww_body(g0, (int)blockIdx.x, nb0, smem);
+  else pf_gemm_bww_body(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, smem);
+}
+// PF_GEMM_BWW=0 falls back to the LDS-staged kernel for the weight-gradient GEMM
+static inline bool pf_gemm_use_bww() { static const bool v = [] { const char* e = getenv("PF_GEMM_BWW"); return e ? atoi(e) != 0 : true; }(); return v; }
+
 // PF_GEMM_PERSIST = resident blocks per CU for the persistent grid (0: one block per tile)
 static inline int pf_gemm_persist() { static const int v = [] { const char* e = getenv("PF_GEMM_PERSIST"); return e ? atoi(e) : 0; }(); return v; }
 template <int BM, int BN>
@@ -299,6 +406,9 @@ template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
 static inline void pf_gemm_launch(const GemmArgs& g_in, int splits, hipStream_t s) {
   GemmArgs g = g_in;
   const int blocks = pf_gemm_blocks<BM, BN>(g, splits);
+  if constexpr (BM == 64 && BN == 64 && !A_KC && !B_KC && EPI == GEMM_EPI_NONE && COLSUM) {
+    if (pf_gemm_use_bww()) { hipLaunchKernelGGL(pf_gemm_bww_kernel, dim3(blocks), dim3(256), 0, s, g); return; }
+  }
   if (pf_gemm_vec<A_KC, B_KC>(g)) hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, true>), dim3(blocks), dim3(256), 0, s, g);
   else hipLaunchKernelGGL((pf_gemm_kernel<BM, BN, A_KC, B_KC, EPI, COLSUM, (A_KC || B_KC) ? false : true>), dim3(blocks), dim3(256), 0, s, g);
 }
@@ -307,6 +417,9 @@ template <bool A_KC, bool B_KC, int EPI, bool COLSUM = false>
 static inline void pf_gemm_launch2(const GemmArgs& g0_in, int splits0, const GemmArgs& g1_in, int splits1, hipStream_t s) {
   GemmArgs g0 = g0_in, g1 = g1_in;
   const int nb0 = pf_gemm_blocks<64, 64>(g0, splits0), nb1 = pf_gemm_blocks<64, 64>(g1, splits1);
+  if constexpr (!A_KC && !B_KC && EPI == GEMM_EPI_NONE && COLSUM) {
+    if (pf_gemm_use_bww()) { hipLaunchKernelGGL(pf_gemm_bww_kernel2, dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0); return; }
+  }
   const bool v0 = pf_gemm_vec<A_KC, B_KC>(g0), v1 = pf_gemm_vec<A_KC, B_KC>(g1);
   constexpr bool HAS_KC = A_KC || B_KC;
   const dim3 grid(nb0 + nb1), block(256);
