@@ -449,12 +449,13 @@ static inline int pf_pick_tile(int M, int N, int K, int splits) {
   return best;
 }
 // Split-K choice for the weight-gradient GEMM (output only out x in, reduction over tens of thousands of rows): measured
-// on MI355X (tools/gemm_sweep_bwdw.py) 64x64 tiles win or tie everywhere and the time is lowest at ~4 blocks per CU
-// (512x256: 83.8 us at 768 blocks, 78.3 at 1024, 85.7 at 1536; 512x148: 74.7 / 58.9 at 768 / 59.7 at 1152; the narrow layers
-// 26 us at 768-1024), so: 64x64 tiles, S = ~1024 blocks / tiles, capped by the slab workspace.
+// on MI355X with the direct-fragment kernel (tools/gemm_sweep_bwdw.py): 512x256: 69.0 us at 512 blocks, 67.7 at 1024,
+// 68.7 at 2048, 74.8 at 4096; 512x148: 59.1 / 47.3 at 768 / 50.7 at 1152; 256x128 and 512x27 (8 tiles): 22.3 / 21.6 at 512
+// blocks, 24.5 / 22.8 at 1024.  So: ~1024 blocks for >= 32 tiles, ~768 for >= 16, ~512 below, capped by the slab workspace.
 static inline void pf_pick_split(int M, int N, int K, int max_splits, int* tile_out, int* splits_out) {
   int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  int S = (1024 + tiles - 1) / tiles;
+  const int target = tiles >= 32 ? 1024 : (tiles >= 16 ? 768 : 512);
+  int S = (target + tiles - 1) / tiles;
   if (S > max_splits) S = max_splits;
   while (S > 1 && (K + S - 1) / S < 64) --S;
   *tile_out = 2; *splits_out = S < 1 ? 1 : S;
