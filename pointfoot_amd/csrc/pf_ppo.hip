@@ -344,6 +344,20 @@ static inline void reduce_slabs(int n, int S, const float* slabs, float* out, hi
   ReduceJob j = reduce_plan(n, S, slabs, out);
   hipLaunchKernelGGL(k_reduce_slabs, dim3(j.blocks), dim3(256), 0, s, j);
 }
+// all slab reductions of one backward pass (both networks, every layer) in ONE launch
+struct ReduceJobs { ReduceJob j[2 * (PPO_MAX_LAYERS + 1)]; int n; };
+__global__ __launch_bounds__(256) void k_reduce_slabs_n(ReduceJobs js) {
+  int b = (int)blockIdx.x;
+  for (int i = 0; i < js.n; ++i) {
+    if (b < js.j[i].blocks) { reduce_job(js.j[i], b); return; }
+    b -= js.j[i].blocks;
+  }
+}
+static inline void reduce_slabs_n(const ReduceJobs& js, hipStream_t s) {
+  int blocks = 0;
+  for (int i = 0; i < js.n; ++i) blocks += js.j[i].blocks;
+  hipLaunchKernelGGL(k_reduce_slabs_n, dim3(blocks), dim3(256), 0, s, js);
+}
 static inline void reduce_slabs2(const ReduceJob& j0, const ReduceJob& j1, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_slabs2, dim3(j0.blocks + j1.blocks), dim3(256), 0, s, j0, j1);
 }
@@ -813,7 +827,7 @@ struct PpoAlg {
   // workspace carve (floats)
   size_t w_xa, w_xc, w_act, w_oldlogp, w_oldmu, w_oldsig, w_adv, w_ret, w_oldval;
   size_t w_ha[PPO_MAX_LAYERS], w_hc[PPO_MAX_LAYERS];   // activations per layer output (last = head output)
-  size_t w_dmean, w_dvalue, w_g[2][PPO_MAX_LAYERS], w_slabs[2], w_partial, w_lastval, w_total;   // [0] actor / [1] critic scratch (run concurrently)
+  size_t w_dmean, w_dvalue, w_g[2][PPO_MAX_LAYERS], w_slabs[2], w_slabl[2][PPO_MAX_LAYERS + 1], w_partial, w_lastval, w_total;   // [0] actor / [1] critic scratch (run concurrently)
   hipStream_t aux = nullptr;        // second stream: the critic network runs beside the actor network
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool dual = true, fused_heads = true;
@@ -878,6 +892,16 @@ static void ppo_plan(PpoAlg* a) {
   for (int k = 0; k < 2; ++k) for (int l = 0; l < PPO_MAX_LAYERS; ++l) a->w_g[k][l] = take(R * mw);
   size_t thin_blocks = (R + 31) / 32;
   for (int k = 0; k < 2; ++k) a->w_slabs[k] = take(std::max<size_t>((size_t)a->splits * (maxw + mw), thin_blocks * (16 * 1024 + 16)));
+  // paired mode: every layer keeps its own slabs so that all reductions of a backward pass run as one launch at its end
+  for (int k = 0; k < 2; ++k) {
+    const Net& n = k == 0 ? a->actor : a->critic;
+    for (int i = 0; i < n.nl; ++i) {
+      const Layer& L = n.l[i];
+      size_t nw = (size_t)L.out * L.in + L.out;
+      if (i == n.nl - 1) a->w_slabl[k][i] = take(thin_blocks * nw);
+      else { int tile, S; pf_pick_split(L.out, L.in, (int)R, a->splits, &tile, &S); a->w_slabl[k][i] = take((size_t)(S + 1) * nw); }
+    }
+  }
   a->w_partial = take(std::max<size_t>((size_t)RED_BLOCKS * 24, thin_blocks * 20));
   a->w_lastval = take(c.num_envs);
   a->w_total = w;
@@ -981,11 +1005,10 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
   const float* X[2] = {Xa, Xc};
   const int last = a->actor.nl - 1;
   auto g_of = [&](int set, int i) { return ws + a->w_g[set][i]; };
+  ReduceJobs js; js.n = 0;
   {   // head gradient slabs written by k_heads
     const int nblk = (M + HEAD_ROWS - 1) / HEAD_ROWS;
-    ReduceJob j[2];
-    for (int k = 0; k < 2; ++k) { const Layer& L = net[k]->l[last]; j[k] = reduce_plan(L.out * L.in + L.out, nblk, ws + a->w_slabs[k], G + L.w); }
-    reduce_slabs2(j[0], j[1], s);
+    for (int k = 0; k < 2; ++k) { const Layer& L = net[k]->l[last]; js.j[js.n++] = reduce_plan(L.out * L.in + L.out, nblk, ws + a->w_slabl[k][last], G + L.w); }
   }
   for (int i = last - 1; i >= 0; --i) {
     if (i > 0) {      // dZ_{i-1} = (g_i W_i) * ELU'(h_{i-1})
@@ -1003,18 +1026,19 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
     for (int k = 0; k < 2; ++k) {
       const Layer& L = net[k]->l[i];
       g[k] = GemmArgs{};
-      g[k].A = g_of(k, i); g[k].B = i == 0 ? X[k] : ws + w_h[k][i - 1]; g[k].C = ws + a->w_slabs[k];
+      g[k].A = g_of(k, i); g[k].B = i == 0 ? X[k] : ws + w_h[k][i - 1]; g[k].C = ws + a->w_slabl[k][i];
       g[k].M = L.out; g[k].N = L.in; g[k].K = M; g[k].lda = L.out; g[k].ldb = L.in; g[k].ldc = L.in;
       int tile, want;
       pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
       int per = ((M + want - 1) / want + 31) / 32 * 32;
       S[k] = (M + per - 1) / per;
       g[k].k_per_split = per;
-      j[k] = reduce_plan(L.out * L.in + L.out, S[k], ws + a->w_slabs[k], G + L.w);
+      j[k] = reduce_plan(L.out * L.in + L.out, S[k], ws + a->w_slabl[k][i], G + L.w);
     }
     pf_gemm_launch2<false, false, GEMM_EPI_NONE, true>(g[1], S[1], g[0], S[0], s);
-    reduce_slabs2(j[1], j[0], s);
+    js.j[js.n++] = j[1]; js.j[js.n++] = j[0];
   }
+  reduce_slabs_n(js, s);      // every layer has its own slabs: one reduction launch for the whole pass
 }
 
 // The actor and the critic are independent networks: run the critic on a second stream so one network's launch tails,
@@ -1246,7 +1270,8 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
                        c.use_clipped_value_loss, ws + a->w_ha[a->actor.nl - 2], ws + a->w_hc[a->critic.nl - 2], a->b.d_params + La.w,
                        a->b.d_params + La.b, a->b.d_params + Lc.w, a->b.d_params + Lc.b, stdp, ws + a->w_act, ws + a->w_oldlogp,
                        ws + a->w_oldmu, ws + a->w_oldsig, ws + a->w_adv, ws + a->w_ret, ws + a->w_oldval,
-                       ws + a->w_g[0][a->actor.nl - 2], ws + a->w_g[1][a->critic.nl - 2], ws + a->w_slabs[0], ws + a->w_slabs[1],
+                       ws + a->w_g[0][a->actor.nl - 2], ws + a->w_g[1][a->critic.nl - 2],
+                       ws + (a->paired ? a->w_slabl[0][a->actor.nl - 1] : a->w_slabs[0]), ws + (a->paired ? a->w_slabl[1][a->critic.nl - 1] : a->w_slabs[1]),
                        ws + a->w_partial);
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, nblk, A, B, c.entropy_coef, ws + a->w_partial, stdp,
                        a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
