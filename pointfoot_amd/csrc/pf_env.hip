@@ -184,6 +184,7 @@ int pf_update_config(PfEnv* e, const PfConfig* cfg) {
 static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, const PfInject* inject, void* stream, int mode) {
   if (!e || !e->bound) { pf_set_error("pf_step: buffers not bound"); return 1; }
   if (mode == 0 && !d_actions) { pf_set_error("pf_step: actions pointer is NULL"); return 1; }
+  { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != e->device) { pf_set_error("pf_step: the calling thread's current HIP device is not the env's device (torch.cuda.set_device)"); return 1; } }
   PfStepArgs g;
   g.model = e->d_model; g.cfg = e->d_cfg; g.L = e->layout; g.b = e->bufs;
   if (inject) g.inj = *inject; else std::memset(&g.inj, 0, sizeof(g.inj));

@@ -979,6 +979,14 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
   }
 }
 
+// kernels launch on the calling thread's current device: it has to be the one the handle was created for
+static bool ppo_wrong_device(const PpoAlg* a) {
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == a->device) return false;
+  pf_set_error("ppo: the calling thread's current HIP device is not the algorithm's device (torch.cuda.set_device)");
+  return true;
+}
+
 // ---- paired execution: layer i of the actor and of the critic go out as ONE launch (pf_gemm_kernel2 / k_reduce_slabs2).
 // Same overlap as two streams -- one problem's tail blocks are filled by the other's -- without cross-stream events
 // (each costs ~10 us on the critical path) and with half the launches.  Needs the same number of layers in both nets.
@@ -1152,6 +1160,7 @@ int ppo_bind_buffers(PpoAlg* a, const PpoBuffers* b) {
 int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs, float* d_actions_out, int64_t sample_counter,
             const float* d_inject_normal, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_act: buffers not bound"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
   const PpoConfig& c = a->cfg;
   if (t < 0 || t >= c.num_steps) { pf_set_error("ppo_act: transition index out of range (rollout buffer overflow)"); return 1; }
   hipStream_t s = (hipStream_t)stream;
@@ -1189,6 +1198,7 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
 
 int ppo_act_inference(PpoAlg* a, const float* d_obs, int32_t n, float* d_actions_out, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_act_inference: buffers not bound"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
   if (n < 1 || n > a->max_rows) { pf_set_error("ppo_act_inference: batch larger than the workspace"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   mlp_forward(a, a->actor, d_obs, n, a->w_ha, s);
@@ -1199,6 +1209,7 @@ int ppo_act_inference(PpoAlg* a, const float* d_obs, int32_t n, float* d_actions
 
 int ppo_process_env_step(PpoAlg* a, int32_t t, const float* d_rew, const uint8_t* d_dones, const uint8_t* d_time_outs, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_process_env_step: buffers not bound"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
   const PpoConfig& c = a->cfg;
   if (t < 0 || t >= c.num_steps) { pf_set_error("ppo_process_env_step: transition index out of range"); return 1; }
   size_t tn = (size_t)t * c.num_envs;
@@ -1211,6 +1222,7 @@ int ppo_process_env_step(PpoAlg* a, int32_t t, const float* d_rew, const uint8_t
 
 int ppo_compute_returns(PpoAlg* a, const float* d_last_critic_obs, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_compute_returns: buffers not bound"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
   const PpoConfig& c = a->cfg;
   hipStream_t s = (hipStream_t)stream;
   float* ws = a->b.d_workspace;
@@ -1228,6 +1240,7 @@ int ppo_compute_returns(PpoAlg* a, const float* d_last_critic_obs, void* stream)
 
 int ppo_normalize_advantages(PpoAlg* a, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_normalize_advantages: buffers not bound"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
   size_t n = (size_t)a->cfg.num_envs * a->cfg.num_steps;
   hipLaunchKernelGGL(k_normalize, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, n, a->b.d_advantages, a->b.d_scalars);
   PPO_HIP_OK(hipGetLastError());
@@ -1236,6 +1249,7 @@ int ppo_normalize_advantages(PpoAlg* a, void* stream) {
 
 int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_minibatch_backward: buffers not bound"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
   const PpoConfig& c = a->cfg;
   if (mb < 0 || mb >= c.num_mini_batches) { pf_set_error("ppo_minibatch_backward: minibatch index out of range"); return 1; }
   hipStream_t s = (hipStream_t)stream;
@@ -1301,6 +1315,7 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
 
 int ppo_minibatch_apply(PpoAlg* a, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_minibatch_apply: buffers not bound"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
   const PpoConfig& c = a->cfg;
   hipStream_t s = (hipStream_t)stream;
   float* ws = a->b.d_workspace;

@@ -392,6 +392,7 @@ class HipEnv:
         self.commands_scale = torch.tensor([c.commands_scale[i] for i in range(3)], device=dev)
         self._load_actuator_network(dev)
         # native handle
+        torch.cuda.set_device(torch.device(dev))        # kernels launch on the thread's current device (checked by the library)
         self._h = lib.pf_create(C.byref(self._model), C.byref(c), torch.device(dev).index or 0)
         if not self._h:
             raise RuntimeError("pf_create failed: " + lib.pf_last_error().decode())

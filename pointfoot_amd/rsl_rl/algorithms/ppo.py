@@ -95,6 +95,7 @@ class PPO:
         ws = lib.ppo_workspace_floats(C.byref(c))
         self.workspace = z(ws)
         self.perm = z(num_envs * num_transitions_per_env, torch.int32)
+        torch.cuda.set_device(torch.device(dev))        # kernels launch on the thread's current device (checked by the library)
         self._h = lib.ppo_create(C.byref(c), torch.device(dev).index or 0)
         if not self._h:
             raise RuntimeError("ppo_create: " + lib.pf_last_error().decode())
