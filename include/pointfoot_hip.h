@@ -37,6 +37,8 @@ extern "C" {
 #define PF_MAX_HPTS 192
 #define PF_MAX_TERM 8
 #define PF_MAX_PEN 20
+#define PF_MAX_CAPS 16         /* collision capsules (pairs of equal-radius spheres on one body; a lone sphere is a capsule of length 0) */
+#define PF_MAX_PAIRS 32        /* self-collision capsule pairs */
 #define PF_STATS_FLOATS (PF_MAX_REWARDS + 4)
 /* actuator network `LSTMsea` (resources/actuator_nets/anydrive_v3_lstm.pt): in_scale(2), out_scale(1), LSTM(2->8) x 2 layers
  * (PyTorch gate order i,f,g,o), Linear(8->1).  Flat parameter block handed over in d_actuator_params: */
@@ -113,6 +115,12 @@ typedef struct PfModel {
   int32_t n_term, n_pen;
   int32_t term_body[PF_MAX_TERM];       /* termination_contact_indices, point_foot.py:963-968 */
   int32_t pen_body[PF_MAX_PEN];         /* penalised_contact_indices,   point_foot.py:956-961 */
+  /* self-collision geometry (asset.self_collisions = 0 enables it, pointfoot_rough_config.py:107, point_foot.py:942):
+   * capsule c spans spheres cap_s0[c] .. cap_s1[c] (same body, same radius); pairs list the capsules that may touch
+   * (bodies on different branches of the tree; a parent-child pair never collides, as in PhysX) */
+  int32_t ncap, npair;
+  int32_t cap_s0[PF_MAX_CAPS], cap_s1[PF_MAX_CAPS];
+  int32_t pair_a[PF_MAX_PAIRS], pair_b[PF_MAX_PAIRS];
 } PfModel;
 
 /* Task constants: everything PointFoot reads from cfg (pointfoot_rough_config.py) after _parse_cfg /
@@ -176,6 +184,12 @@ typedef struct PfConfig {
   int32_t use_actuator_net;      /* cfg.control.use_actuator_network anymal.py:71-78 */
   float cmd_lo[4], cmd_hi[4];    /* ranges: lin_vel_x, lin_vel_y, ang_vel_yaw, heading   legged_robot.py:343-349 */
   float max_push_vel;            /* cfg.domain_rand.max_push_vel_xy  legged_robot.py:417 */
+  /* trimesh collision surface (legged_gym/utils/terrain.py:69-73, point_foot.py:852-868): height steps steeper than
+   * slope_treshold become vertical faces.  wall_threshold = slope_treshold * horizontal_scale in metres of height per
+   * grid step; 0 = plain bilinear height field (mesh_type 'heightfield', or a plane) */
+  float wall_threshold;
+  int32_t self_collisions;       /* 1: leg-leg capsule contacts on (asset.self_collisions == 0) */
+  float joint_friction_vel;      /* regularisation speed of the Coulomb joint friction (rad/s); see d_joint_friction */
 } PfConfig;
 
 /* Per-env state record: one contiguous row of `rec_floats` floats per env (AoS: a wavefront owns
@@ -213,6 +227,14 @@ typedef struct PfBuffers {
   const float* d_actuator_params; /* LeggedRobot + actuator net: PF_ACT_PARAMS floats (see PF_ACT_* offsets) or NULL */
   float* d_reset_stats;        /* (PF_STATS_FLOATS,): [i] = sum of episode_sums[i] over the envs reset this step
                                   (point_foot.py:276-280), [PF_MAX_REWARDS] = number of envs reset; zeroed by pf_step */
+  const float* d_joint_friction; /* (N, nd) Coulomb joint friction torque per DOF (update_frictions, point_foot.py:103-108:
+                                  dof_props["friction"]) or NULL = none */
+  uint64_t* d_contact_set;     /* (N, decimation, 3) or NULL.  Diagnostic output for parity tests, the discrete decisions of
+                                  substep `sub`: word 0 = bit c set when contact candidate c was active (candidates: floor
+                                  contact of sphere s = s, vertical-face contact of sphere s = nsph + s, capsule pair
+                                  p = 2 nsph + p); word 1 = joint-limit rows, 2 bits per DOF (1: at the lower, 2: at the upper limit); word 2 = sum
+                                  over the kept terrain contacts of (candidate + 1) * (4 * grid cell + face): which cell of
+                                  the (piecewise, stepped) collision surface each contact was evaluated in */
 } PfBuffers;
 
 /* Optional injected inputs (parity tests).  All NULL in production. */
@@ -255,6 +277,10 @@ int pf_step(PfEnv* env, const float* d_actions, int64_t step_counter, const PfIn
 /* replaces: reset_idx(arange(N)) of PointFoot.reset() (point_foot.py:137-139); the zero-action step of
  * :140-141 is a separate pf_step call made by the host. */
 int pf_reset_all(PfEnv* env, int64_t step_counter, const PfInject* inject, void* stream);
+
+/* replaces: reset_idx(env_ids) for a subset (point_foot.py:249-299; scripted single-env resets, e.g.
+ * scripts/simulate_trajectory.py:72-97).  d_mask (N,) bytes: non-zero = reset this env.  Same launch as pf_reset_all. */
+int pf_reset_idx(PfEnv* env, const uint8_t* d_mask, int64_t step_counter, const PfInject* inject, void* stream);
 
 /* replaces: compute_observations() re-run by update_cmd (point_foot.py:123-129) */
 int pf_compute_observations(PfEnv* env, int64_t step_counter, const PfInject* inject, void* stream);

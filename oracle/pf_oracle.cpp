@@ -213,32 +213,102 @@ const int MAXC = 6;                              // contacts kept per robot (fir
 const int MAXROWS = 3 * MAXC + PF_MAX_DOF;
 const int NVMAX = 6 + PF_MAX_DOF;
 
+// Collision surface (own model; the reference hands PhysX a triangle mesh built by
+// isaacgym.terrain_utils.convert_heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_scale, slope_treshold),
+// call site legged_gym/utils/terrain.py:69-73 -- closed package, parity unpinned).  That conversion slides the low vertex of
+// every grid edge steeper than slope_treshold under its high neighbour, so the step becomes a vertical face at the high
+// vertex's grid line and the ground next to it stays at the low height.  Restated per grid cell:
+//   * floor: bilinear over the cell's corner heights, where a corner more than wall_threshold above the cell's lowest
+//     corner counts as the top of a face and takes the low height;
+//   * faces: on each of the cell's four grid lines a vertical face stands where the raw profile along that line is more
+//     than wall_threshold above the floor profile; a sphere touches the nearest point of the face segment (so the lip of
+//     a step is a rounded edge).  One face candidate per sphere: the closest.
+// wall_threshold == 0 (mesh_type 'heightfield'): plain bilinear field, no faces.
 template <typename R>
 struct Terrain {
-  // bilinear height + normal of the collision height field (own choice; reference collides a trimesh)
-  static void query(const Ctx& x, R wx, R wy, R* h, V3<R>* n) {
+  struct Hit { R h; V3<R> n; bool wall; V3<R> wn; R wdist; long cell; int face; };
+  static Hit query(const Ctx& x, int ix0, int iy0, R lx, R ly, R wz, R rad) {
     const PfConfig& c = *x.c;
-    if (c.terrain_type == PF_TERRAIN_PLANE || !x.b->d_height_samples) { *h = 0; *n = {0, 0, 1}; return; }
-    R fx = (wx + (R)c.border) / (R)c.hscale, fy = (wy + (R)c.border) / (R)c.hscale;
-    fx = std::min(std::max(fx, (R)0), (R)(c.hf_rows - 1) - (R)1e-3);
-    fy = std::min(std::max(fy, (R)0), (R)(c.hf_cols - 1) - (R)1e-3);
-    int ix = (int)fx, iy = (int)fy;
-    R tx = fx - ix, ty = fy - iy;
+    Hit o; o.h = 0; o.n = {0, 0, 1}; o.wall = false; o.wn = {0, 0, 1}; o.wdist = (R)1e9; o.cell = 0; o.face = 0;
+    if (c.terrain_type == PF_TERRAIN_PLANE || !x.b->d_height_samples) return o;
+    // (lx, ly): metres from the corner of grid cell (ix0, iy0) -- see the anchor in pfo_step
+    R fx = lx / (R)c.hscale, fy = ly / (R)c.hscale;
+    R ox = std::floor(fx), oy = std::floor(fy);
+    int ix = ix0 + (int)ox, iy = iy0 + (int)oy;
+    R tx = fx - ox, ty = fy - oy;
+    if (ix < 0) { ix = 0; tx = 0; } else if (ix > c.hf_rows - 2) { ix = c.hf_rows - 2; tx = (R)1 - (R)1e-3; }
+    if (iy < 0) { iy = 0; ty = 0; } else if (iy > c.hf_cols - 2) { iy = c.hf_cols - 2; ty = (R)1 - (R)1e-3; }
+    o.cell = (long)ix * c.hf_cols + iy;
     const int16_t* hs = x.b->d_height_samples;
-    R h00 = hs[ix * c.hf_cols + iy], h10 = hs[(ix + 1) * c.hf_cols + iy], h01 = hs[ix * c.hf_cols + iy + 1],
-      h11 = hs[(ix + 1) * c.hf_cols + iy + 1];
-    R vs = (R)c.vscale;
-    *h = vs * ((1 - tx) * ((1 - ty) * h00 + ty * h01) + tx * ((1 - ty) * h10 + ty * h11));
-    R dhdx = vs * ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / (R)c.hscale;
-    R dhdy = vs * ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / (R)c.hscale;
+    R vs = (R)c.vscale, hsc = (R)c.hscale;
+    R H00 = vs * hs[ix * c.hf_cols + iy], H10 = vs * hs[(ix + 1) * c.hf_cols + iy], H01 = vs * hs[ix * c.hf_cols + iy + 1],
+      H11 = vs * hs[(ix + 1) * c.hf_cols + iy + 1];
+    R E00 = H00, E10 = H10, E01 = H01, E11 = H11;
+    const R thr = (R)c.wall_threshold;
+    if (thr > 0) {
+      R lo = std::min(std::min(H00, H10), std::min(H01, H11));
+      if (H00 - lo > thr) E00 = lo;
+      if (H10 - lo > thr) E10 = lo;
+      if (H01 - lo > thr) E01 = lo;
+      if (H11 - lo > thr) E11 = lo;
+    }
+    o.h = (1 - tx) * ((1 - ty) * E00 + ty * E01) + tx * ((1 - ty) * E10 + ty * E11);
+    R dhdx = ((1 - ty) * (E10 - E00) + ty * (E11 - E01)) / hsc;
+    R dhdy = ((1 - tx) * (E01 - E00) + tx * (E11 - E10)) / hsc;
     R inv = 1 / std::sqrt(dhdx * dhdx + dhdy * dhdy + 1);
-    *n = {-dhdx * inv, -dhdy * inv, inv};
+    o.n = {-dhdx * inv, -dhdy * inv, inv};
+    if (thr > 0) {
+      // faces on the cell's grid lines: 0: x-far (normal -x), 1: x-near (+x), 2: y-far (-y), 3: y-near (+y)
+      const R top[4] = {(1 - ty) * H10 + ty * H11, (1 - ty) * H00 + ty * H01, (1 - tx) * H01 + tx * H11, (1 - tx) * H00 + tx * H10};
+      const R bot[4] = {(1 - ty) * E10 + ty * E11, (1 - ty) * E00 + ty * E01, (1 - tx) * E01 + tx * E11, (1 - tx) * E00 + tx * E10};
+      const R gap[4] = {(1 - tx) * hsc, tx * hsc, (1 - ty) * hsc, ty * hsc};
+      for (int f = 0; f < 4; ++f) {
+        if (!(top[f] - bot[f] > thr)) continue;
+        R dz = std::max(wz - top[f], (R)0);
+        R len = std::sqrt(gap[f] * gap[f] + dz * dz);
+        R dist = len - rad;
+        if (dist < o.wdist) {
+          R il = 1 / std::max(len, (R)1e-9);
+          R hn = len > (R)1e-9 ? gap[f] * il : (R)1, zn = len > (R)1e-9 ? dz * il : (R)0;
+          o.wall = true; o.wdist = dist; o.face = f;
+          o.wn = f == 0 ? V3<R>{-hn, 0, zn} : f == 1 ? V3<R>{hn, 0, zn} : f == 2 ? V3<R>{0, -hn, zn} : V3<R>{0, hn, zn};
+        }
+      }
+    }
+    return o;
   }
 };
 
+// closest points of the segments p1-q1 and p2-q2 (Ericson, Real-Time Collision Detection 5.1.9); returns c1 - c2 and the
+// point c2
+template <typename R>
+inline V3<R> segment_segment(V3<R> p1, V3<R> q1, V3<R> p2, V3<R> q2, V3<R>* c2_out) {
+  const R eps = (R)1e-12;
+  V3<R> d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+  R a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+  R s, t;
+  auto clamp01 = [](R v) { return std::min(std::max(v, (R)0), (R)1); };
+  if (a <= eps && e <= eps) { s = 0; t = 0; }
+  else if (a <= eps) { s = 0; t = clamp01(f / e); }
+  else {
+    R cc = dot(d1, r);
+    if (e <= eps) { t = 0; s = clamp01(-cc / a); }
+    else {
+      R b = dot(d1, d2), den = a * e - b * b;
+      s = den > eps ? clamp01((b * f - cc * e) / den) : (R)0;
+      t = (b * s + f) / e;
+      if (t < 0) { t = 0; s = clamp01(-cc / a); }
+      else if (t > 1) { t = 1; s = clamp01((b - cc) / a); }
+    }
+  }
+  V3<R> c1 = p1 + s * d1, c2 = p2 + t * d2;
+  *c2_out = c2;
+  return c1 - c2;
+}
+
 // One physics substep of sim_dt.  Reads/writes root, dof_pos, dof_vel, contact_forces, feet_pos in S.
 template <typename R>
-void physics_substep(const Ctx& x, float* S, bool apply_ext) {
+void physics_substep(const Ctx& x, float* S, bool apply_ext, int env, int sub, int ix0, int iy0) {
   const PfModel& m = *x.m; const PfConfig& c = *x.c; const PfLayout& L = *x.L;
   const int nb = m.nb, nd = m.nd, nv = 6 + nd;
   const R dt = (R)c.sim_dt;
@@ -376,49 +446,86 @@ void physics_substep(const Ctx& x, float* S, bool apply_ext) {
   for (int k = 0; k < nd; ++k) vel[6 + k] = qd[k];
   for (int a = 0; a < nv; ++a) rhs[a] = -bias[a];
   for (int k = 0; k < nd; ++k) rhs[6 + k] += (R)S[L.torques + k];
+  if (x.b->d_joint_friction) {   // regularised Coulomb joint friction (update_frictions, point_foot.py:103-108)
+    for (int k = 0; k < nd; ++k) {
+      R u = qd[k] / (R)c.joint_friction_vel;
+      rhs[6 + k] -= (R)x.b->d_joint_friction[(size_t)env * nd + k] * std::min(std::max(u, (R)-1), (R)1);
+    }
+  }
   solve(rhs, dv);
   for (int a = 0; a < nv; ++a) vel[a] += dt * dv[a];
 
   // ---- constraint rows: contacts (n, t1, t2) then joint limits
   struct Row { R J[NVMAX]; R MinvJ[NVMAX]; R Ainv; R b; R lam; };
   static thread_local Row rows[MAXROWS];
-  struct Contact { int body; V3<R> n, t1, t2; R mu; R A[3][3]; };
+  struct Contact { int body, body_b; V3<R> n, t1, t2; R mu; R A[3][3]; };
   Contact cons[MAXC];
   int ncon = 0, nrows = 0;
+  uint64_t cset = 0, cells = 0;
   const R mu_env = (R)0.5 * ((R)S[L.friction] + (R)c.terrain_friction);
   const R rest = (R)0.5 * (R)c.terrain_restitution;
-  for (int s = 0; s < m.nsph && ncon < MAXC; ++s) {
+  // contact candidates in a fixed order -- floor contact of sphere s (candidate s), vertical-face contact of sphere s
+  // (nsph + s), self-collision capsule pair p (2 nsph + p) -- the first MAXC active ones are kept
+  V3<R> sphc[PF_MAX_SPHERES];                     // sphere centres relative to the base origin
+  typename Terrain<R>::Hit hit[PF_MAX_SPHERES];
+  for (int s = 0; s < m.nsph; ++s) {
     int i = m.sph_body[s];
     V3<R> sp = {(R)m.sph_pos[s][0], (R)m.sph_pos[s][1], (R)m.sph_pos[s][2]};
-    V3<R> xs = r[i] + mul(Rw[i], sp);
-    R h; V3<R> n;
-    Terrain<R>::query(x, pos.x + xs.x, pos.y + xs.y, &h, &n);
-    R dist = (pos.z + xs.z - h) * n.z - (R)m.sph_radius[s];
+    sphc[s] = r[i] + mul(Rw[i], sp);
+    hit[s] = Terrain<R>::query(x, ix0, iy0, pos.x + sphc[s].x, pos.y + sphc[s].y, pos.z + sphc[s].z, (R)m.sph_radius[s]);
+  }
+  const int ncand = 2 * m.nsph + (c.self_collisions ? m.npair : 0);
+  for (int cand = 0; cand < ncand && ncon < MAXC; ++cand) {
+    int i, ib = -1; V3<R> n, xc; R dist;
+    if (cand < 2 * m.nsph) {
+      const int s = cand < m.nsph ? cand : cand - m.nsph;
+      const bool wall = cand >= m.nsph;
+      i = m.sph_body[s];
+      if (wall) { if (!hit[s].wall) continue; n = hit[s].wn; dist = hit[s].wdist; }
+      else { n = hit[s].n; dist = (pos.z + sphc[s].z - hit[s].h) * n.z - (R)m.sph_radius[s]; }
+      xc = sphc[s] - (R)m.sph_radius[s] * n;
+    } else {
+      const int p = cand - 2 * m.nsph, ca = m.pair_a[p], cb = m.pair_b[p];
+      i = m.sph_body[m.cap_s0[ca]]; ib = m.sph_body[m.cap_s0[cb]];
+      const R ra = (R)m.sph_radius[m.cap_s0[ca]], rb = (R)m.sph_radius[m.cap_s0[cb]];
+      V3<R> c2;
+      V3<R> v = segment_segment(sphc[m.cap_s0[ca]], sphc[m.cap_s1[ca]], sphc[m.cap_s0[cb]], sphc[m.cap_s1[cb]], &c2);
+      R len = std::sqrt(dot(v, v));
+      dist = len - ra - rb;
+      n = len > (R)1e-9 ? ((R)1 / len) * v : V3<R>{0, 1, 0};      // from capsule b towards capsule a
+      xc = c2 + (rb + (R)0.5 * dist) * n;                          // middle of the gap / overlap
+    }
     if (!(dist < (R)c.contact_offset)) continue;
-    V3<R> xc = xs - (R)m.sph_radius[s] * n;
+    cset |= (uint64_t)1 << cand;
+    if (cand < 2 * m.nsph) { const int s = cand < m.nsph ? cand : cand - m.nsph; cells += (uint64_t)(cand + 1) * (uint64_t)(4 * hit[s].cell + (cand < m.nsph ? 0 : hit[s].face)); }
     // tangent basis
     V3<R> ref = std::fabs(n.x) < (R)0.9 ? V3<R>{1, 0, 0} : V3<R>{0, 1, 0};
     V3<R> t1 = cross(n, ref); R il = 1 / std::sqrt(dot(t1, t1)); t1 = il * t1;
     V3<R> t2 = cross(n, t1);
     Contact& C = cons[ncon];
-    C.body = i; C.n = n; C.t1 = t1; C.t2 = t2; C.mu = mu_env;
+    C.body = i; C.body_b = ib; C.n = n; C.t1 = t1; C.t2 = t2; C.mu = mu_env;
     V3<R> dirs[3] = {n, t1, t2};
     for (int d = 0; d < 3; ++d) {
       Row& rw = rows[nrows + d];
       for (int a = 0; a < nv; ++a) rw.J[a] = 0;
       V3<R> dd = dirs[d];
-      rw.J[0] = dd.x; rw.J[1] = dd.y; rw.J[2] = dd.z;
-      V3<R> xa = cross(xc, dd);
-      rw.J[3] = xa.x; rw.J[4] = xa.y; rw.J[5] = xa.z;
+      if (ib < 0) {      // against the terrain: the base columns see the contact point
+        rw.J[0] = dd.x; rw.J[1] = dd.y; rw.J[2] = dd.z;
+        V3<R> xa = cross(xc, dd);
+        rw.J[3] = xa.x; rw.J[4] = xa.y; rw.J[5] = xa.z;
+      }
       for (int j = i; j > 0; j = m.parent[j]) {
         int kj = m.dof_of_body[j];
         if (kj < 0) continue;
-        rw.J[6 + kj] = dot(ax[j], cross(xc - r[j], dd));
+        rw.J[6 + kj] += dot(ax[j], cross(xc - r[j], dd));
+      }
+      for (int j = ib; j > 0; j = m.parent[j]) {      // relative velocity of body a against body b at the same point
+        int kj = m.dof_of_body[j];
+        if (kj < 0) continue;
+        rw.J[6 + kj] -= dot(ax[j], cross(xc - r[j], dd));
       }
       rw.lam = 0; rw.b = 0;
     }
-    // normal target velocity
-    R un = 0; for (int a = 0; a < nv; ++a) un += rows[nrows].J[a] * vel[a];
     R bn;
     if (dist >= 0) bn = -dist / dt;
     else bn = std::min((R)0.2 * (-dist) / dt, (R)c.max_depenetration_vel);
@@ -427,12 +534,12 @@ void physics_substep(const Ctx& x, float* S, bool apply_ext) {
             rows[nrows].J[4] * wb.y + rows[nrows].J[5] * wb.z;
     for (int k = 0; k < nd; ++k) un0 += rows[nrows].J[6 + k] * qd[k];
     if (un0 < -(R)c.bounce_threshold) bn = std::max(bn, -rest * un0);
-    (void)un;
     rows[nrows].b = bn;
     nrows += 3; ++ncon;
   }
   const int ncrow = nrows;
   int lim_dof[PF_MAX_DOF]; int nlim = 0;
+  uint64_t lset = 0;
   for (int k = 0; k < nd; ++k) {
     R qn = q[k] + dt * vel[6 + k];
     R lo = m.q_lo[k], hi = m.q_hi[k];
@@ -446,6 +553,12 @@ void physics_substep(const Ctx& x, float* S, bool apply_ext) {
     rw.b = viol > 0 ? std::min((R)0.2 * viol / dt, (R)c.max_depenetration_vel * 10) : viol / dt;
     rw.lam = 0;
     lim_dof[nlim++] = k; ++nrows;
+    lset |= (uint64_t)(side > 0 ? 1 : 2) << (2 * k);
+  }
+  if (x.b->d_contact_set) {
+    x.b->d_contact_set[((size_t)env * c.decimation + sub) * 3] = cset;
+    x.b->d_contact_set[((size_t)env * c.decimation + sub) * 3 + 1] = lset;
+    x.b->d_contact_set[((size_t)env * c.decimation + sub) * 3 + 2] = cells;
   }
   for (int rI = 0; rI < nrows; ++rI) {
     solve(rows[rI].J, rows[rI].MinvJ);
@@ -514,6 +627,11 @@ void physics_substep(const Ctx& x, float* S, bool apply_ext) {
     S[L.contact_forces + 3 * C.body + 0] += (float)F.x;
     S[L.contact_forces + 3 * C.body + 1] += (float)F.y;
     S[L.contact_forces + 3 * C.body + 2] += (float)F.z;
+    if (C.body_b >= 0) {      // self-contact: the opposite force on the other link
+      S[L.contact_forces + 3 * C.body_b + 0] -= (float)F.x;
+      S[L.contact_forces + 3 * C.body_b + 1] -= (float)F.y;
+      S[L.contact_forces + 3 * C.body_b + 2] -= (float)F.z;
+    }
   }
 }
 
@@ -857,13 +975,27 @@ int pfo_step(const PfModel* model, const PfConfig* cfg, const PfLayout* layout, 
       for (int i = 0; i < model->nb * 3; ++i) S[L.contact_forces + i] = inject->d_contact[(size_t)env * model->nb * 3 + i];
       for (int i = 0; i < model->nfeet * 3; ++i) S[L.feet_pos + i] = inject->d_feet_pos[(size_t)env * model->nfeet * 3 + i];
     } else {
+      // The substeps run in coordinates local to the grid cell the base starts the step in: S[root], S[root + 1] hold
+      // metres from that cell's corner, so contact geometry is resolved to ~1e-7 m wherever the env sits on the field
+      // (float32 world coordinates are only good to 4e-6 m at 50 m from the origin).  The world position gets the step's
+      // displacement added once at the end.
+      const float gx = S[L.root], gy = S[L.root + 1];
+      int ix0 = 0, iy0 = 0;
+      if (c.terrain_type != PF_TERRAIN_PLANE && bufs->d_height_samples) {
+        const float cx = (gx + c.border) / c.hscale, cy = (gy + c.border) / c.hscale;
+        const float bx = std::floor(cx), by = std::floor(cy);
+        ix0 = (int)bx; iy0 = (int)by;
+        S[L.root] = (cx - bx) * c.hscale; S[L.root + 1] = (cy - by) * c.hscale;
+      }
+      const float lx0 = S[L.root], ly0 = S[L.root + 1];
       for (int sub = 0; sub < c.decimation; ++sub) {   // :180-185
         if (c.env_kind == PF_KIND_LEGGED_ROBOT && c.use_actuator_net && bufs->d_actuator_params) actuator_torques(x, S);
         else compute_torques(x, S, S + L.dof_pos, S + L.dof_vel);
         bool ext = sub == 0 && S[L.ext_force + 3] != 0.0f;
-        if (physics_bits == 64) physics_substep<double>(x, S, ext); else physics_substep<float>(x, S, ext);
+        if (physics_bits == 64) physics_substep<double>(x, S, ext, env, sub, ix0, iy0); else physics_substep<float>(x, S, ext, env, sub, ix0, iy0);
         if (ext) S[L.ext_force + 3] = 0.0f;
       }
+      S[L.root] = gx + (S[L.root] - lx0); S[L.root + 1] = gy + (S[L.root + 1] - ly0);
       if (physics_bits == 64) feet_positions<double>(x, S); else feet_positions<float>(x, S);
     }
     post_physics(x, env, S);

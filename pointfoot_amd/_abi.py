@@ -15,6 +15,8 @@ PF_MAX_OBS = 256
 PF_MAX_HPTS = 192
 PF_MAX_TERM = 8
 PF_MAX_PEN = 20
+PF_MAX_CAPS = 16
+PF_MAX_PAIRS = 32
 PPO_MAX_LAYERS = 4
 PF_STATS_FLOATS = PF_MAX_REWARDS + 4
 PF_ACT_PARAMS = 972
@@ -46,6 +48,8 @@ class PfModel(C.Structure):
         ("sph_radius", f32 * PF_MAX_SPHERES),
         ("feet_body", i32 * PF_MAX_FEET), ("n_term", i32), ("n_pen", i32),
         ("term_body", i32 * PF_MAX_TERM), ("pen_body", i32 * PF_MAX_PEN),
+        ("ncap", i32), ("npair", i32), ("cap_s0", i32 * PF_MAX_CAPS), ("cap_s1", i32 * PF_MAX_CAPS),
+        ("pair_a", i32 * PF_MAX_PAIRS), ("pair_b", i32 * PF_MAX_PAIRS),
     ]
 
 
@@ -78,6 +82,7 @@ class PfConfig(C.Structure):
         ("seed_lo", u32), ("seed_hi", u32),
         ("env_kind", i32), ("resample_interval", i32), ("use_actuator_net", i32),
         ("cmd_lo", f32 * 4), ("cmd_hi", f32 * 4), ("max_push_vel", f32),
+        ("wall_threshold", f32), ("self_collisions", i32), ("joint_friction_vel", f32),
     ]
 
 
@@ -98,7 +103,7 @@ class PfBuffers(C.Structure):
     _fields_ = [(n, vp) for n in (
         "d_state", "d_episode_length", "d_terrain_level", "d_terrain_type", "d_reset", "d_time_out", "d_terminate",
         "d_obs", "d_priv", "d_rew", "d_measured_heights", "d_height_samples", "d_terrain_origins", "d_actuator_params",
-        "d_reset_stats")]
+        "d_reset_stats", "d_joint_friction", "d_contact_set")]
 
 
 class PfInject(C.Structure):
@@ -165,9 +170,10 @@ def load():
     lib.pf_set_reset_stats_next.restype = i32
     lib.pf_step.argtypes = [vp, vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_reset_all.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
+    lib.pf_reset_idx.argtypes = [vp, vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_compute_observations.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
     _bind_ppo(lib)
-    for fn in ("pf_bind_buffers", "pf_update_config", "pf_step", "pf_reset_all", "pf_compute_observations"):
+    for fn in ("pf_bind_buffers", "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations"):
         getattr(lib, fn).restype = i32
     _LIB = lib
     return lib
@@ -204,7 +210,7 @@ def check(rc, lib=None):
 
 EXPORTED_SYMBOLS = [
     "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers", "pf_set_reset_stats", "pf_set_reset_stats_next",
-    "pf_update_config", "pf_step", "pf_reset_all", "pf_compute_observations",
+    "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations",
     "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act",
     "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",
     "ppo_minibatch_backward", "ppo_minibatch_apply"]

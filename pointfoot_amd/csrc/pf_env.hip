@@ -100,6 +100,17 @@ static int pf_validate(const PfModel* m, const PfConfig* c) {
     pf_set_error("pf_create: configuration outside the compiled limits");
     return 1;
   }
+  if (m->ncap < 0 || m->npair < 0 || m->ncap > PF_MAX_CAPS || m->npair > PF_MAX_PAIRS ||
+      (inst == 0 && (m->ncap > PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::KC || m->npair > PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::KP)) ||
+      (inst == 1 && (c->self_collisions || m->npair > 0))) {
+    pf_set_error("pf_create: self-collision geometry outside the compiled limits (PointFoot: 8 capsules / 16 pairs; LeggedRobot: none)");
+    return 1;
+  }
+  for (int p = 0; p < m->npair; ++p)
+    if (m->pair_a[p] < 0 || m->pair_a[p] >= m->ncap || m->pair_b[p] < 0 || m->pair_b[p] >= m->ncap) { pf_set_error("pf_create: capsule pair index out of range"); return 1; }
+  for (int k = 0; k < m->ncap; ++k)
+    if (m->cap_s0[k] < 0 || m->cap_s0[k] >= m->nsph || m->cap_s1[k] < 0 || m->cap_s1[k] >= m->nsph) { pf_set_error("pf_create: capsule sphere index out of range"); return 1; }
+  if (2 * m->nsph + m->npair > 64) { pf_set_error("pf_create: more than 64 contact candidates"); return 1; }
   if (inst == 1 && c->num_priv_obs != 0) { pf_set_error("pf_create: LeggedRobot has no privileged observations"); return 1; }
   for (int i = 1; i < m->nb; ++i)
     if (m->parent[i] < 0 || m->parent[i] >= i) { pf_set_error("pf_create: bodies must be in depth-first order"); return 1; }
@@ -181,7 +192,7 @@ int pf_update_config(PfEnv* e, const PfConfig* cfg) {
   return 0;
 }
 
-static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, const PfInject* inject, void* stream, int mode) {
+static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, const PfInject* inject, void* stream, int mode, const uint8_t* d_mask = nullptr) {
   if (!e || !e->bound) { pf_set_error("pf_step: buffers not bound"); return 1; }
   if (mode == 0 && !d_actions) { pf_set_error("pf_step: actions pointer is NULL"); return 1; }
   { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != e->device) { pf_set_error("pf_step: the calling thread's current HIP device is not the env's device (torch.cuda.set_device)"); return 1; } }
@@ -191,7 +202,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   if (g.inj.d_root && !(g.inj.d_dof_pre && g.inj.d_dof_post && g.inj.d_contact && g.inj.d_feet_pos)) {
     pf_set_error("pf_step: incomplete injected sim state"); return 1;
   }
-  g.actions = d_actions; g.step_counter = step_counter; g.mode = mode; g.stamps = e->d_stamps;
+  g.actions = d_actions; g.step_counter = step_counter; g.mode = mode; g.stamps = e->d_stamps; g.reset_mask = d_mask;
   hipStream_t s = (hipStream_t)stream;
   g.stats_next = nullptr;
   if (e->bufs.d_reset_stats && mode != 2) {
@@ -231,6 +242,10 @@ int pf_step(PfEnv* e, const float* d_actions, int64_t step_counter, const PfInje
 }
 int pf_reset_all(PfEnv* e, int64_t step_counter, const PfInject* inject, void* stream) {
   return pf_launch(e, nullptr, step_counter, inject, stream, 1);
+}
+int pf_reset_idx(PfEnv* e, const uint8_t* d_mask, int64_t step_counter, const PfInject* inject, void* stream) {
+  if (!d_mask) { pf_set_error("pf_reset_idx: mask pointer is NULL (use pf_reset_all)"); return 1; }
+  return pf_launch(e, nullptr, step_counter, inject, stream, 1, d_mask);
 }
 int pf_compute_observations(PfEnv* e, int64_t step_counter, const PfInject* inject, void* stream) {
   return pf_launch(e, nullptr, step_counter, inject, stream, 2);

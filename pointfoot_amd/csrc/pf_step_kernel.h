@@ -126,6 +126,7 @@ struct PfStepArgs {
   int mode;               // 0 = step, 1 = reset_idx(all), 2 = compute_observations only
   unsigned* stamps;       // diagnostic build only, else NULL
   float* stats_next;      // next step's statistics slot, cleared by this launch (NULL: the host clears slots itself)
+  const uint8_t* reset_mask;   // mode 1 only: envs to reset (NULL: all) -- reset_idx(env_ids), point_foot.py:249
 };
 
 template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1>
@@ -136,6 +137,10 @@ struct PfKernel {
   static constexpr int NV = 6 + ND;
   static constexpr int NVP = NV | 1;          // odd row stride: per-lane rows hit distinct LDS banks
   static constexpr int MAXC = PF_MAXC;
+  // self-collision capsules / capsule pairs this instance is built for (PointFoot: 2 legs x 4 links; the LeggedRobot tasks
+  // of the reference switch self-collision off, anymal_c_rough_config.py:77)
+  static constexpr int KC = LR ? 1 : 8, KP = LR ? 1 : 16;
+  static constexpr bool SELF = !LR;
   static constexpr int CROWS = 3 * MAXC;
   static constexpr int RFREE = CROWS + ND;    // extra right-hand side: free acceleration
   static constexpr int NROWS = RFREE + 1;
@@ -196,6 +201,7 @@ struct PfKernel {
     float q_lo[ND], q_hi[ND], vel_limit[ND];
     int sph_body[KS];
     float sph_pos[KS][3], sph_radius[KS];
+    int ncap, npair, cap_s0[KC], cap_s1[KC], pair_a[KP], pair_b[KP];
     // root-to-leaf chains (one lane walks one chain in forward kinematics) and per-body 'fixed rotation is identity' flags
     int nchain, chain_len[PF_MAX_CHAINS], chain[PF_MAX_CHAINS][PF_MAX_CHAIN_DEPTH], rot_ident[NB];
   };
@@ -213,19 +219,29 @@ struct PfKernel {
     float rec[REC_MAX];
     float gates[LR ? ND * 32 : 1];            // LSTM gate pre-activations
     float Rw[NB][9], r[NB][3], ax[NB][3];
-    float Sj[NB][6], V[NB][6], A[NB][6];      // {ang, lin@O}
-    float I[NB][10], Ic[NB][10];
-    float f[NB][6], fc[NB][6];                // {moment@O, force}
-    float F[ND][6];
+    // The dynamics scratch (dead once the mass matrix and the bias are built) and the contact candidates (born after the
+    // factorisation, dead after the contact rows) share storage.
+    union {
+      struct {
+        float Sj[NB][6], V[NB][6], A[NB][6];      // {ang, lin@O}
+        float I[NB][10], Ic[NB][10];
+        float f[NB][6], fc[NB][6];                // {moment@O, force}
+        float F[ND][6];
+      };
+      struct {
+        float sphc[KS][3];                        // sphere centres relative to the base origin
+        float cn[2 * KS][3], cd[2 * KS];          // normal / signed distance: floor candidate s at [s], face candidate at [KS + s]
+        float pn[KP][3], px[KP][3], pd[KP];       // capsule pairs: normal (b -> a), contact point, distance
+        int ccell[KS];                            // 4 * grid cell + face of the sphere's terrain query (diagnostic word)
+      };
+    };
     float M[NV][NVP];
     float dinv[NV];
     float bias[NV], vel[NV], vold[NV];
     float J[NROWS][NVP], W[NROWS][NVP];
     float rb[NROWS], rAinv[NROWS], lam[NROWS];
     float cA[MAXC][9], cdir[MAXC][9];
-    int cbody[MAXC], con_sph[MAXC], lim_dof[ND], lim_side[ND];
-    float sphx[KS][3], sphn[KS][3], sphd[KS];
-    int sphact[KS];
+    int cbody[MAXC], cbody_b[MAXC], con_cand[MAXC], lim_dof[ND], lim_side[ND];
   };
   // the height scan (post-physics only) reuses the constraint-row storage (physics only)
   static_assert(NROWS * NVP >= PF_MAX_HPTS, "height scan does not fit the aliased row storage");
@@ -247,20 +263,85 @@ struct PfKernel {
     h = h < h3 ? h : h3;
     return (float)h;
   }
-  // collision surface: bilinear height + normal (own contact model)
-  PF_DEV void terrain_query(const PfConfig& c, const int16_t* hs, float wx, float wy, float* h, float* n) {
+  // Collision surface (own contact model; the reference hands PhysX the trimesh of terrain.py:69-73).  Floor: bilinear over
+  // the cell's corners, a corner more than wall_threshold above the cell's lowest corner taking the low height (it is the
+  // top of a vertical face).  Faces: on each of the cell's four grid lines, where the raw profile stands more than
+  // wall_threshold above the floor profile; the sphere touches the nearest point of the face segment.  Returns the floor
+  // height / normal and the closest face (wd = 1e9: none).  Same arithmetic as oracle/pf_oracle.cpp Terrain::query.
+  PF_DEV void terrain_query(const PfConfig& c, const int16_t* hs, int ix0, int iy0, float lx, float ly, float wz, float rad, float* h, float* n, float* wn, float* wd, int* cellface) {
+    *cellface = 0;
+    *wd = 1e9f; wn[0] = 0.0f; wn[1] = 0.0f; wn[2] = 1.0f;
     if (c.terrain_type == PF_TERRAIN_PLANE || hs == nullptr) { *h = 0.0f; n[0] = 0.0f; n[1] = 0.0f; n[2] = 1.0f; return; }
-    float fx = (wx + c.border) / c.hscale, fy = (wy + c.border) / c.hscale;
-    fx = fminf(fmaxf(fx, 0.0f), (float)(c.hf_rows - 1) - 1e-3f);
-    fy = fminf(fmaxf(fy, 0.0f), (float)(c.hf_cols - 1) - 1e-3f);
-    int ix = (int)fx, iy = (int)fy;
-    float tx = fx - (float)ix, ty = fy - (float)iy;
-    float h00 = hs[ix * c.hf_cols + iy], h10 = hs[(ix + 1) * c.hf_cols + iy], h01 = hs[ix * c.hf_cols + iy + 1], h11 = hs[(ix + 1) * c.hf_cols + iy + 1];
-    *h = c.vscale * ((1.0f - tx) * ((1.0f - ty) * h00 + ty * h01) + tx * ((1.0f - ty) * h10 + ty * h11));
-    float dhdx = c.vscale * ((1.0f - ty) * (h10 - h00) + ty * (h11 - h01)) / c.hscale;
-    float dhdy = c.vscale * ((1.0f - tx) * (h01 - h00) + tx * (h11 - h10)) / c.hscale;
+    // (lx, ly): metres from the corner of grid cell (ix0, iy0), the anchor of this step's local coordinates (run())
+    const float fx = lx / c.hscale, fy = ly / c.hscale;
+    const float ox = floorf(fx), oy = floorf(fy);
+    int ix = ix0 + (int)ox, iy = iy0 + (int)oy;
+    float tx = fx - ox, ty = fy - oy;
+    if (ix < 0) { ix = 0; tx = 0.0f; } else if (ix > c.hf_rows - 2) { ix = c.hf_rows - 2; tx = 1.0f - 1e-3f; }
+    if (iy < 0) { iy = 0; ty = 0.0f; } else if (iy > c.hf_cols - 2) { iy = c.hf_cols - 2; ty = 1.0f - 1e-3f; }
+    *cellface = 4 * (ix * c.hf_cols + iy);
+    const float vs = c.vscale, hsc = c.hscale, thr = c.wall_threshold;
+    const float H00 = vs * (float)hs[ix * c.hf_cols + iy], H10 = vs * (float)hs[(ix + 1) * c.hf_cols + iy],
+                H01 = vs * (float)hs[ix * c.hf_cols + iy + 1], H11 = vs * (float)hs[(ix + 1) * c.hf_cols + iy + 1];
+    float E00 = H00, E10 = H10, E01 = H01, E11 = H11;
+    if (thr > 0.0f) {
+      const float lo = fminf(fminf(H00, H10), fminf(H01, H11));
+      E00 = (H00 - lo > thr) ? lo : H00; E10 = (H10 - lo > thr) ? lo : H10;
+      E01 = (H01 - lo > thr) ? lo : H01; E11 = (H11 - lo > thr) ? lo : H11;
+    }
+    *h = (1.0f - tx) * ((1.0f - ty) * E00 + ty * E01) + tx * ((1.0f - ty) * E10 + ty * E11);
+    float dhdx = ((1.0f - ty) * (E10 - E00) + ty * (E11 - E01)) / hsc;
+    float dhdy = ((1.0f - tx) * (E01 - E00) + tx * (E11 - E10)) / hsc;
     float inv = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
     n[0] = -dhdx * inv; n[1] = -dhdy * inv; n[2] = inv;
+    if (thr > 0.0f) {
+      // 0: x-far (normal -x), 1: x-near (+x), 2: y-far (-y), 3: y-near (+y)
+      const float top[4] = {(1.0f - ty) * H10 + ty * H11, (1.0f - ty) * H00 + ty * H01, (1.0f - tx) * H01 + tx * H11, (1.0f - tx) * H00 + tx * H10};
+      const float bot[4] = {(1.0f - ty) * E10 + ty * E11, (1.0f - ty) * E00 + ty * E01, (1.0f - tx) * E01 + tx * E11, (1.0f - tx) * E00 + tx * E10};
+      const float gap[4] = {(1.0f - tx) * hsc, tx * hsc, (1.0f - ty) * hsc, ty * hsc};
+      float best = 1e9f, bh = 1.0f, bz = 0.0f; int bf = -1;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const float dz = fmaxf(wz - top[f], 0.0f);
+        const float len = sqrtf(gap[f] * gap[f] + dz * dz);
+        const float dist = len - rad;
+        const bool take = (top[f] - bot[f] > thr) && dist < best;
+        const float il = 1.0f / fmaxf(len, 1e-9f);
+        const bool deg = !(len > 1e-9f);
+        best = take ? dist : best; bf = take ? f : bf;
+        bh = take ? (deg ? 1.0f : gap[f] * il) : bh; bz = take ? (deg ? 0.0f : dz * il) : bz;
+      }
+      if (bf >= 0) {
+        *wd = best; *cellface += bf;
+        wn[0] = bf == 0 ? -bh : (bf == 1 ? bh : 0.0f);
+        wn[1] = bf == 2 ? -bh : (bf == 3 ? bh : 0.0f);
+        wn[2] = bz;
+      }
+    }
+  }
+  // closest points of two segments (Ericson 5.1.9): v = c1 - c2, and c2
+  PF_DEV void segment_segment(const float* p1, const float* q1, const float* p2, const float* q2, float* v, float* c2) {
+    const float eps = 1e-12f;
+    float d1[3], d2[3], r[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { d1[t] = q1[t] - p1[t]; d2[t] = q2[t] - p2[t]; r[t] = p1[t] - p2[t]; }
+    const float a = pf_dot3(d1, d1), e = pf_dot3(d2, d2), f = pf_dot3(d2, r);
+    float sp, tp;
+    if (a <= eps && e <= eps) { sp = 0.0f; tp = 0.0f; }
+    else if (a <= eps) { sp = 0.0f; tp = pf_clip(f / e, 0.0f, 1.0f); }
+    else {
+      const float cc = pf_dot3(d1, r);
+      if (e <= eps) { tp = 0.0f; sp = pf_clip(-cc / a, 0.0f, 1.0f); }
+      else {
+        const float b = pf_dot3(d1, d2), den = a * e - b * b;
+        sp = den > eps ? pf_clip((b * f - cc * e) / den, 0.0f, 1.0f) : 0.0f;
+        tp = (b * sp + f) / e;
+        if (tp < 0.0f) { tp = 0.0f; sp = pf_clip(-cc / a, 0.0f, 1.0f); }
+        else if (tp > 1.0f) { tp = 1.0f; sp = pf_clip((b - cc) / a, 0.0f, 1.0f); }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { c2[t] = p2[t] + tp * d2[t]; v[t] = (p1[t] + sp * d1[t]) - c2[t]; }
   }
 
   PF_DEV float rnd(const PfConfig& c, const PfLayout& L, const PfInject& inj, int env, long long step, int slot) {
@@ -425,7 +506,7 @@ struct PfKernel {
   }
 
   // ------------------------------------------------------------------ one physics substep of sim_dt
-  PF_DEV void substep(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, bool apply_ext) {
+  PF_DEV void substep(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, bool apply_ext, int env, int sub, int ix0, int iy0) {
     float* S = sh.rec;
     const float dt = c.sim_dt;
     kinematics<true>(sh, m, c, L);
@@ -529,6 +610,8 @@ struct PfKernel {
       }
       sh.bias[a] = bv; sh.vold[a] = vo;
       float rhs = -bv + (a >= 6 ? S[LC::torques + a - 6] : 0.0f);
+      if (B.d_joint_friction && a >= 6)     // regularised Coulomb joint friction (update_frictions, :103-108)
+        rhs -= B.d_joint_friction[(size_t)env * ND + a - 6] * pf_clip(vo / c.joint_friction_vel, -1.0f, 1.0f);
       sh.J[RFREE][a] = rhs; sh.W[RFREE][a] = rhs;
     }
     PF_SYNC();
@@ -602,29 +685,78 @@ struct PfKernel {
       }
     }
     PF_STAMP(sh, 4);
-    // ---- contact candidates: every collision sphere against the terrain
+    // ---- contact candidates, in a fixed order: floor contact of sphere s (candidate s), vertical-face contact of sphere s
+    //      (nsph + s), self-collision capsule pair p (2 nsph + p); the first MAXC active ones are kept
     const int16_t* hs = B.d_height_samples;
-    PF_LANES(s, m.nsph) {
+    const int nsph = m.nsph;
+    PF_LANES(s, nsph) {
       int i = m.sph_body[s];
       float xs[3]; pf_mat_vec(sh.Rw[i], m.sph_pos[s], xs);
       for (int t = 0; t < 3; ++t) xs[t] += sh.r[i][t];
-      float h, n[3];
-      terrain_query(c, hs, S[LC::root] + xs[0], S[LC::root + 1] + xs[1], &h, n);
+      float h, n[3], wn[3], wd;
+      int cellface;
       float rad = m.sph_radius[s];
-      float dist = (S[LC::root + 2] + xs[2] - h) * n[2] - rad;
-      sh.sphact[s] = dist < c.contact_offset ? 1 : 0;
-      sh.sphd[s] = dist;
-      for (int t = 0; t < 3; ++t) { sh.sphx[s][t] = xs[t] - rad * n[t]; sh.sphn[s][t] = n[t]; }
+      terrain_query(c, hs, ix0, iy0, S[LC::root] + xs[0], S[LC::root + 1] + xs[1], S[LC::root + 2] + xs[2], rad, &h, n, wn, &wd, &cellface);
+      sh.ccell[s] = cellface;
+      sh.cd[s] = (S[LC::root + 2] + xs[2] - h) * n[2] - rad;
+      sh.cd[KS + s] = wd;
+      for (int t = 0; t < 3; ++t) { sh.sphc[s][t] = xs[t]; sh.cn[s][t] = n[t]; sh.cn[KS + s][t] = wn[t]; }
     }
     PF_SYNC();
+    int npair = 0;
+    if constexpr (SELF) {
+      npair = c.self_collisions ? m.npair : 0;
+      PF_LANES(p, npair) {
+        const int ca = m.pair_a[p], cb = m.pair_b[p];
+        const int a0 = m.cap_s0[ca], b0 = m.cap_s0[cb];
+        float v[3], c2[3];
+        segment_segment(sh.sphc[a0], sh.sphc[m.cap_s1[ca]], sh.sphc[b0], sh.sphc[m.cap_s1[cb]], v, c2);
+        const float len = sqrtf(pf_dot3(v, v)), rb = m.sph_radius[b0];
+        const float dist = len - m.sph_radius[a0] - rb;
+        const bool ok = len > 1e-9f;
+        const float il = 1.0f / fmaxf(len, 1e-9f);
+        float n[3] = {ok ? v[0] * il : 0.0f, ok ? v[1] * il : 1.0f, ok ? v[2] * il : 0.0f};
+        sh.pd[p] = dist;
+        for (int t = 0; t < 3; ++t) { sh.pn[p][t] = n[t]; sh.px[p][t] = c2[t] + (rb + 0.5f * dist) * n[t]; }
+      }
+      PF_SYNC();
+    }
+    const int ncand = 2 * nsph + npair;
+    auto cand_dist = [&](int cand) { return cand < nsph ? sh.cd[cand] : (cand < 2 * nsph ? sh.cd[KS + cand - nsph] : sh.pd[SELF ? cand - 2 * nsph : 0]); };
     int ncon = 0;
-    for (int s = 0; s < m.nsph; ++s) ncon += sh.sphact[s];
-    ncon = ncon < MAXC ? ncon : MAXC;
-    PF_LANES(s, m.nsph) {
-      if (!sh.sphact[s]) continue;
-      int idx = 0;
-      for (int t = 0; t < s; ++t) idx += sh.sphact[t];
-      if (idx < MAXC) { sh.con_sph[idx] = s; sh.cbody[idx] = m.sph_body[s]; }
+    unsigned long long cset = 0ull;
+#if !defined(PF_HOST_EMU)
+    {
+      // compaction by ballot: lane l tests candidates l, l + PF_W, ...; its slot is the number of active candidates before it
+      const unsigned long long below = (1ull << PF_LANE_ID) - 1ull;
+      const int half_shift = (PF_W == 64) ? 0 : ((int)threadIdx.x & 32);
+      for (int c0 = 0; c0 < ncand; c0 += PF_W) {
+        const int cand = c0 + PF_LANE_ID;
+        const bool act = cand < ncand && cand_dist(cand) < c.contact_offset;
+        unsigned long long grp = __ballot(act) >> half_shift;
+        if (PF_W < 64) grp &= 0xFFFFFFFFull;
+        const int idx = ncon + __popcll(grp & below);
+        if (act && idx < MAXC) sh.con_cand[idx] = cand;
+        ncon += __popcll(grp);
+        cset |= grp << c0;
+      }
+    }
+#else
+    for (int cand = 0; cand < ncand; ++cand)
+      if (cand_dist(cand) < c.contact_offset) { if (ncon < MAXC) sh.con_cand[ncon] = cand; ++ncon; cset |= 1ull << cand; }
+#endif
+    if (ncon > MAXC) {      // candidates beyond the cap are not contacts: drop them from the reported set
+      unsigned long long kept = 0ull, rest = cset;
+      for (int t = 0; t < MAXC; ++t) { kept |= rest & (~rest + 1ull); rest &= rest - 1ull; }
+      cset = kept; ncon = MAXC;
+    }
+    if (B.d_contact_set) {      // diagnostic (parity tests): which candidates were kept, and in which cell / on which face
+      unsigned long long cells = 0ull;
+      for (int ci = 0; ci < ncon; ++ci) {
+        const int cand = sh.con_cand[ci];
+        if (cand < 2 * nsph) { const int cf = sh.ccell[cand < nsph ? cand : cand - nsph]; cells += (unsigned long long)(cand + 1) * (unsigned long long)(cand < nsph ? (cf & ~3) : cf); }
+      }
+      PF_ONE { B.d_contact_set[((size_t)env * c.decimation + sub) * 3] = cset; B.d_contact_set[((size_t)env * c.decimation + sub) * 3 + 2] = cells; }
     }
     PF_SYNC();
     PF_STAMP(sh, 5);
@@ -632,8 +764,21 @@ struct PfKernel {
     const float rest = 0.5f * c.terrain_restitution;
     PF_LANES(rr, 3 * ncon) {
       int ci = rr / 3, d = rr - 3 * ci;
-      int s = sh.con_sph[ci], i = m.sph_body[s];
-      float n[3] = {sh.sphn[s][0], sh.sphn[s][1], sh.sphn[s][2]};
+      const int cand = sh.con_cand[ci];
+      int i, ib = -1;
+      float n[3], xc[3], dist;
+      if (cand < 2 * nsph) {
+        const int s = cand < nsph ? cand : cand - nsph, slot = cand < nsph ? cand : KS + s;
+        i = m.sph_body[s];
+        const float rad = m.sph_radius[s];
+        dist = sh.cd[slot];
+        for (int t = 0; t < 3; ++t) { n[t] = sh.cn[slot][t]; xc[t] = sh.sphc[s][t] - rad * n[t]; }
+      } else {
+        const int p = SELF ? cand - 2 * nsph : 0;
+        i = m.sph_body[m.cap_s0[m.pair_a[p]]]; ib = m.sph_body[m.cap_s0[m.pair_b[p]]];
+        dist = sh.pd[p];
+        for (int t = 0; t < 3; ++t) { n[t] = sh.pn[p][t]; xc[t] = sh.px[p][t]; }
+      }
       float ref[3] = {fabsf(n[0]) < 0.9f ? 1.0f : 0.0f, fabsf(n[0]) < 0.9f ? 0.0f : 1.0f, 0.0f};
       float t1[3]; pf_cross(n, ref, t1);
       float il = 1.0f / sqrtf(pf_dot3(t1, t1));
@@ -642,20 +787,24 @@ struct PfKernel {
       float dd[3];
       for (int t = 0; t < 3; ++t) dd[t] = d == 0 ? n[t] : (d == 1 ? t1[t] : t2[t]);
       for (int t = 0; t < 3; ++t) sh.cdir[ci][3 * d + t] = dd[t];
-      float xc[3] = {sh.sphx[s][0], sh.sphx[s][1], sh.sphx[s][2]};
+      if (d == 0) { sh.cbody[ci] = i; sh.cbody_b[ci] = ib; }
       float row[NV];
 #pragma unroll
       for (int a = 0; a < NV; ++a) row[a] = 0.0f;
-      row[0] = dd[0]; row[1] = dd[1]; row[2] = dd[2];
+      const float gnd = ib < 0 ? 1.0f : 0.0f;       // against the terrain the base columns see the contact point
+      row[0] = gnd * dd[0]; row[1] = gnd * dd[1]; row[2] = gnd * dd[2];
       float xa[3]; pf_cross(xc, dd, xa);
-      row[3] = xa[0]; row[4] = xa[1]; row[5] = xa[2];
+      row[3] = gnd * xa[0]; row[4] = gnd * xa[1]; row[5] = gnd * xa[2];
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
         int j = m.body_of_dof[k];
-        if (j <= i && i < j + m.subtree[j]) {
+        // +1 for an ancestor of body a, -1 for an ancestor of body b (relative velocity at the shared contact point)
+        float sg = (j <= i && i < j + m.subtree[j]) ? 1.0f : 0.0f;
+        if (SELF) sg -= (j <= ib && ib < j + m.subtree[j]) ? 1.0f : 0.0f;
+        if (sg != 0.0f) {
           float rel[3] = {xc[0] - sh.r[j][0], xc[1] - sh.r[j][1], xc[2] - sh.r[j][2]};
           float cr[3]; pf_cross(rel, dd, cr);
-          row[6 + k] = pf_dot3(sh.ax[j], cr);
+          row[6 + k] = sg * pf_dot3(sh.ax[j], cr);
         }
       }
       float un0 = 0.0f;
@@ -663,7 +812,6 @@ struct PfKernel {
       for (int a = 0; a < NV; ++a) { sh.J[rr][a] = row[a]; sh.W[rr][a] = row[a]; un0 += row[a] * sh.vold[a]; }
       float bn = 0.0f;
       if (d == 0) {
-        float dist = sh.sphd[s];
         bn = dist >= 0.0f ? -dist / dt : fminf(0.2f * (-dist) / dt, c.max_depenetration_vel);
         if (un0 < -c.bounce_threshold) bn = fmaxf(bn, -rest * un0);
       }
@@ -688,6 +836,11 @@ struct PfKernel {
     PF_SYNC();
     int nlim = 0;
     for (int k = 0; k < ND; ++k) nlim += sh.lim_side[k] != 0 ? 1 : 0;
+    if (B.d_contact_set) {      // diagnostic (parity tests): which joint-limit rows are active
+      unsigned long long lset = 0ull;
+      for (int k = 0; k < ND; ++k) lset |= (unsigned long long)(sh.lim_side[k] > 0 ? 1 : (sh.lim_side[k] < 0 ? 2 : 0)) << (2 * k);
+      PF_ONE { B.d_contact_set[((size_t)env * c.decimation + sub) * 3 + 1] = lset; }
+    }
     PF_LANES(k, ND) {
       int side = sh.lim_side[k];
       if (side == 0) continue;
@@ -848,9 +1001,10 @@ struct PfKernel {
     PF_LANES(i, NB) {
       float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
       for (int ci = 0; ci < ncon; ++ci) {
-        if (sh.cbody[ci] != i) continue;
+        const float sg = sh.cbody[ci] == i ? 1.0f : ((SELF && sh.cbody_b[ci] == i) ? -1.0f : 0.0f);   // a self-contact pushes the two links apart
+        if (sg == 0.0f) continue;
         for (int d = 0; d < 3; ++d) {
-          float l = sh.lam[3 * ci + d] / dt;
+          float l = sg * sh.lam[3 * ci + d] / dt;
           Fx += l * sh.cdir[ci][3 * d]; Fy += l * sh.cdir[ci][3 * d + 1]; Fz += l * sh.cdir[ci][3 * d + 2];
         }
       }
@@ -1030,6 +1184,7 @@ struct PfKernel {
   PF_DEV void run(Shared& sh, SharedRO& ro, const PfStepArgs& g, int env) {
     const PfModel& gm = *g.model; const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
     ModelS& ms = ro.mdl;
+    if (g.mode == 1 && g.reset_mask && !g.reset_mask[env]) return;      // reset_idx(env_ids): this env is not in the subset
 #if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
     if (threadIdx.x == 0) { sh.stamp_last = __builtin_amdgcn_s_memtime(); for (int t = 0; t < PF_NSTAMP; ++t) sh.stamp_acc[t] = 0; }
 #endif
@@ -1046,9 +1201,11 @@ struct PfKernel {
       for (int t = 0; t < 3; ++t) ms.sph_pos[s2][t] = gm.sph_pos[s2][t];
     }
     PF_LANES(f, NF) ms.feet_body[f] = gm.feet_body[f];
+    PF_LANES(t, KC) { ms.cap_s0[t] = gm.cap_s0[t]; ms.cap_s1[t] = gm.cap_s1[t]; }
+    PF_LANES(t, KP) { ms.pair_a[t] = gm.pair_a[t]; ms.pair_b[t] = gm.pair_b[t]; }
     PF_LANES(t, PF_MAX_TERM) ms.term_body[t] = gm.term_body[t];
     PF_LANES(t, PF_MAX_PEN) ms.pen_body[t] = gm.pen_body[t];
-    PF_ONE { ms.nsph = gm.nsph; ms.n_term = gm.n_term; ms.n_pen = gm.n_pen; }
+    PF_ONE { ms.nsph = gm.nsph; ms.n_term = gm.n_term; ms.n_pen = gm.n_pen; ms.ncap = gm.ncap; ms.npair = gm.npair; }
     if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { PF_LANES(i, PF_ACT_PARAMS) ro.act[i] = B.d_actuator_params[i]; } }
     const ModelS& m = ms;
     float* S = sh.rec;
@@ -1102,6 +1259,25 @@ struct PfKernel {
       PF_LANES(i, NF * 3) S[LC::feet_pos + i] = inj.d_feet_pos[(size_t)env * NF * 3 + i];
       PF_SYNC();
     } else {
+      // The substeps run in coordinates local to the grid cell the base starts the step in: S[root], S[root + 1] hold metres
+      // from that cell's corner, so contact geometry is resolved to ~1e-7 m wherever the env sits on the field (float32
+      // world coordinates are only good to 4e-6 m at 50 m from the origin).  The world position gets the step's
+      // displacement added once at the end.  (Same arithmetic as the oracle's pfo_step.)
+      const float gx = S[LC::root], gy = S[LC::root + 1];
+      int ix0 = 0, iy0 = 0;
+      float lx0 = gx, ly0 = gy;
+      if (c.terrain_type != PF_TERRAIN_PLANE && B.d_height_samples) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+        const float cx = (gx + c.border) / c.hscale, cy = (gy + c.border) / c.hscale;
+        const float bx = floorf(cx), by = floorf(cy);
+        ix0 = (int)bx; iy0 = (int)by;
+        lx0 = (cx - bx) * c.hscale; ly0 = (cy - by) * c.hscale;
+      }
+      PF_SYNC();
+      PF_ONE { S[LC::root] = lx0; S[LC::root + 1] = ly0; }
+      PF_SYNC();
       for (int sub = 0; sub < c.decimation; ++sub) {     // :180-185
         PF_STAMP(sh, 0);
         bool pd = true;
@@ -1109,8 +1285,14 @@ struct PfKernel {
         if (pd) torques(sh, c, L, S + LC::dof_pos, 1, LC::dof_vel - LC::dof_pos);
         PF_STAMP(sh, 12);
         bool ext = sub == 0 && S[LC::ext_force + 3] != 0.0f;
-        substep(sh, m, c, L, B, ext);
+        substep(sh, m, c, L, B, ext, env, sub, ix0, iy0);
         if (ext) { PF_ONE { S[LC::ext_force + 3] = 0.0f; } PF_SYNC(); }
+      }
+      {
+        const float nx = gx + (S[LC::root] - lx0), ny = gy + (S[LC::root + 1] - ly0);
+        PF_SYNC();
+        PF_ONE { S[LC::root] = nx; S[LC::root + 1] = ny; }
+        PF_SYNC();
       }
       kinematics<false>(sh, m, c, L);
       PF_LANES(e, NF * 3) { int f = e / 3, t = e - 3 * f; S[LC::feet_pos + e] = S[LC::root + t] + sh.r[m.feet_body[f]][t]; }

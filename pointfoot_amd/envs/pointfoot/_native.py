@@ -61,6 +61,44 @@ def build_model(cfg):
             m.sph_pos[s][k] = p[k]
     for f, b in enumerate(feet):
         m.feet_body[f] = b
+    # self-collision geometry (asset.self_collisions == 0 enables it: pointfoot_rough_config.py:107, point_foot.py:942).
+    # Capsules = the two equal-radius end spheres a cylinder / limb box became (urdf.py), or a single sphere; pairs =
+    # capsules on different branches of the tree (PhysX never collides a parent with its child; links of one chain
+    # cannot reach each other within the joint limits and are left out).
+    caps, pairs = [], []
+    legged_robot = hasattr(cfg.env, "num_observations")
+    if getattr(cfg.asset, "self_collisions", 1) == 0 and legged_robot:
+        # only anymal_c_flat asks for it among the LeggedRobot tasks (anymal_c_flat_config.py:42); config 5
+        # (anymal_c_rough) switches it off (anymal_c_rough_config.py:77)
+        import warnings
+        warnings.warn("asset.self_collisions = 0: the LeggedRobot kernel instance is built without self-collision "
+                      "(12 capsules / 54 pairs on a quadruped); the links of this robot can pass through each other")
+    elif getattr(cfg.asset, "self_collisions", 1) == 0:
+        by_body = {}
+        for s, (b, p, r) in enumerate(sph):
+            if b != 0 and r > 0.0:
+                by_body.setdefault(b, []).append(s)
+        for b in sorted(by_body):
+            ss = by_body[b]
+            if len(ss) == 2 and sph[ss[0]][2] == sph[ss[1]][2]:
+                caps.append((ss[0], ss[1]))
+            else:
+                caps.extend((s, s) for s in ss)
+
+        def related(a, b):      # a is an ancestor of b (or the same body)
+            return a <= b < a + t["subtree"][a]
+        for i in range(len(caps)):
+            for j in range(i + 1, len(caps)):
+                ba, bb = sph[caps[i][0]][0], sph[caps[j][0]][0]
+                if not related(ba, bb) and not related(bb, ba):
+                    pairs.append((i, j))
+        if len(caps) > _abi.PF_MAX_CAPS or len(pairs) > _abi.PF_MAX_PAIRS:
+            raise ValueError(f"self-collision geometry too large for the kernel build: {len(caps)} capsules / {len(pairs)} pairs")
+    m.ncap, m.npair = len(caps), len(pairs)
+    for i, (a, b) in enumerate(caps):
+        m.cap_s0[i], m.cap_s1[i] = a, b
+    for i, (a, b) in enumerate(pairs):
+        m.pair_a[i], m.pair_b[i] = a, b
     m.n_term, m.n_pen = len(term), len(pen)
     for i, b in enumerate(term):
         m.term_body[i] = b
@@ -240,6 +278,10 @@ def build_config(cfg, model, info, sim_params, num_envs, *, env_index_base=0, nu
     c.max_depenetration_vel = px_.max_depenetration_velocity
     c.solver_iterations = px_.num_position_iterations
     c.seed_lo, c.seed_hi = seed & 0xFFFFFFFF, 0x9E3779B9
+    # trimesh: steps steeper than slope_treshold are vertical faces (terrain.py:69-73); a 'heightfield' stays bilinear
+    c.wall_threshold = float(cfg.terrain.slope_treshold) * float(cfg.terrain.horizontal_scale) if mesh == 'trimesh' else 0.0
+    c.self_collisions = int(model.npair > 0)
+    c.joint_friction_vel = 0.1
     if LR:      # legged_robot.py:323, 343-349, 417; anymal.py:52
         c.resample_interval = int(cfg.commands.resampling_time / dt)
         rg = cfg.commands.ranges

@@ -49,7 +49,7 @@ def emu_lib():
            out, srcs)
     lib = C.CDLL(out)
     lib.pfe_step.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfConfig), C.POINTER(_abi.PfLayout),
-                             C.POINTER(_abi.PfBuffers), C.c_void_p, C.c_longlong, C.POINTER(_abi.PfInject), C.c_int]
+                             C.POINTER(_abi.PfBuffers), C.c_void_p, C.c_longlong, C.POINTER(_abi.PfInject), C.c_int, C.c_void_p]
     lib.pfe_layout.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfConfig), C.POINTER(_abi.PfLayout)]
     return lib
 
@@ -105,6 +105,8 @@ class HostSim:
         self.hf = None if hf is None else np.ascontiguousarray(hf, np.int16)
         self.terrain_origins = None if terrain_origins is None else np.ascontiguousarray(terrain_origins, np.float32)
         self.stats = np.zeros(_abi.PF_STATS_FLOATS, np.float32)
+        self.contact_set = np.zeros((n, self.c.decimation, 3), np.uint64)  # diagnostic: contact candidates / joint-limit rows / cells per substep
+        self.joint_friction = None                                          # (n, nd) float32 or None
         self.bufs = self.make_bufs()
 
     def make_bufs(self):
@@ -119,6 +121,8 @@ class HostSim:
         b.d_terrain_origins = p(self.terrain_origins)
         b.d_actuator_params = p(self.actuator)
         b.d_reset_stats = p(self.stats)
+        b.d_contact_set = p(self.contact_set)
+        b.d_joint_friction = p(self.joint_friction)
         return b
 
     def f(self, name, width=None):
@@ -130,12 +134,12 @@ class HostSim:
         import copy
         other = copy.copy(self)
         for k in ("state", "episode_length", "terrain_level", "terrain_type", "reset", "time_out", "terminate", "obs",
-                  "priv", "rew", "heights", "stats"):
+                  "priv", "rew", "heights", "stats", "contact_set"):
             setattr(other, k, getattr(self, k).copy())
         other.bufs = other.make_bufs()
         return other
 
-    def step(self, backend, actions, counter, inject=None, physics_bits=32, mode=0):
+    def step(self, backend, actions, counter, inject=None, physics_bits=32, mode=0, reset_mask=None):
         actions = np.ascontiguousarray(actions, np.float32)
         inj = inject if inject is not None else None
         if backend == "oracle":
@@ -144,7 +148,8 @@ class HostSim:
                                        actions.ctypes.data, counter, inj, physics_bits)
         elif backend == "emu":
             rc = emu_lib().pfe_step(C.byref(self.model), C.byref(self.c), C.byref(self.L), C.byref(self.bufs),
-                                    actions.ctypes.data, counter, inj, mode)
+                                    actions.ctypes.data, counter, inj, mode,
+                                    None if reset_mask is None else np.ascontiguousarray(reset_mask, np.uint8).ctypes.data)
         else:
             raise ValueError(backend)
         assert rc == 0
@@ -214,7 +219,7 @@ def inject_from_golden(g, t, sim, keep):
 class HipMirror:
     """Runs a HostSim's buffers through the real HIP library: upload -> pf_step -> download."""
     FIELDS = ("state", "episode_length", "terrain_level", "terrain_type", "reset", "time_out", "terminate", "obs",
-              "priv", "rew", "heights", "stats")
+              "priv", "rew", "heights", "stats", "contact_set")
 
     def __init__(self, sim, device="cuda:0"):
         import torch
@@ -224,7 +229,9 @@ class HipMirror:
         self.lib = _abi.load()
         self.t = {}
         for k in self.FIELDS:
-            self.t[k] = torch.from_numpy(getattr(sim, k).copy()).to(device)
+            a = getattr(sim, k)
+            self.t[k] = torch.from_numpy((a.view(np.int64) if a.dtype == np.uint64 else a).copy()).to(device)
+        self.t["jf"] = None if sim.joint_friction is None else torch.from_numpy(sim.joint_friction).to(device)
         self.t["hf"] = None if sim.hf is None else torch.from_numpy(sim.hf).to(device)
         self.t["to"] = None if sim.terrain_origins is None else torch.from_numpy(sim.terrain_origins).to(device)
         self.h = self.lib.pf_create(C.byref(sim.model), C.byref(sim.c), 0)
@@ -241,6 +248,8 @@ class HipMirror:
         t["act"] = None if sim.actuator is None else torch.from_numpy(sim.actuator).to(device)
         b.d_actuator_params = p(t["act"])
         b.d_reset_stats = p(t["stats"])
+        b.d_contact_set = p(t["contact_set"])
+        b.d_joint_friction = p(t["jf"])
         self.b = b
         _abi.check(self.lib.pf_bind_buffers(self.h, C.byref(b)), self.lib)
         Lh = _abi.PfLayout()
@@ -249,14 +258,16 @@ class HipMirror:
 
     def upload(self):
         for k in self.FIELDS:
-            self.t[k].copy_(self.torch.from_numpy(getattr(self.sim, k)))
+            a = getattr(self.sim, k)
+            self.t[k].copy_(self.torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a))
 
     def download(self):
         self.torch.cuda.synchronize()
         for k in self.FIELDS:
-            getattr(self.sim, k)[...] = self.t[k].cpu().numpy()
+            a = getattr(self.sim, k)
+            a[...] = self.t[k].cpu().numpy().view(a.dtype)
 
-    def step(self, actions, counter, inject_arrays=None, mode=0):
+    def step(self, actions, counter, inject_arrays=None, mode=0, reset_mask=None):
         torch = self.torch
         a = torch.from_numpy(np.ascontiguousarray(actions, np.float32)).to(self.dev)
         inj = None
@@ -268,8 +279,10 @@ class HipMirror:
                 keep.append(tt)
                 setattr(inj, k, _native.ptr(tt))
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        mask_t = None if reset_mask is None else torch.from_numpy(np.ascontiguousarray(reset_mask, np.uint8)).to(self.dev)
         fn = {0: lambda: self.lib.pf_step(self.h, a.data_ptr(), counter, inj, stream),
-              1: lambda: self.lib.pf_reset_all(self.h, counter, inj, stream),
+              1: lambda: (self.lib.pf_reset_all(self.h, counter, inj, stream) if reset_mask is None else
+                          self.lib.pf_reset_idx(self.h, mask_t.data_ptr(), counter, inj, stream)),
               2: lambda: self.lib.pf_compute_observations(self.h, counter, inj, stream)}[mode]
         _abi.check(fn(), self.lib)
         self.download()
@@ -278,3 +291,34 @@ class HipMirror:
         if self.h:
             self.lib.pf_destroy(self.h)
             self.h = None
+
+
+class EmuMirror:
+    """Debug aid: the HipMirror interface on top of the host build of the step program, so the `-m gpu` env tests can be
+    rehearsed on a machine without a GPU (`PF_TEST_EMU=1 pytest -m gpu tests/test_gpu_env.py`).  Proves nothing about
+    the GPU; the round's GPU tests run with the real library."""
+    FIELDS = HipMirror.FIELDS
+
+    def __init__(self, sim, device=None):
+        self.sim = sim
+
+    def upload(self):
+        pass
+
+    def download(self):
+        pass
+
+    def step(self, actions, counter, inject_arrays=None, mode=0, reset_mask=None):
+        inj = None
+        if inject_arrays is not None:
+            inj = _abi.PfInject()
+            for k, arr in inject_arrays.items():
+                setattr(inj, k, _native.ptr(arr))
+        self.sim.step("emu", actions, counter, inject=inj, mode=mode, reset_mask=reset_mask)
+
+    def close(self):
+        pass
+
+
+if os.environ.get("PF_TEST_EMU") == "1":
+    HipMirror = EmuMirror

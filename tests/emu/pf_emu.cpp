@@ -6,11 +6,11 @@
 #include "../../pointfoot_amd/csrc/pf_layout.h"
 
 extern "C" int pfe_step(const PfModel* model, const PfConfig* cfg, const PfLayout* layout, const PfBuffers* bufs,
-                        const float* actions, long long step_counter, const PfInject* inject, int mode) {
+                        const float* actions, long long step_counter, const PfInject* inject, int mode, const unsigned char* reset_mask) {
   PfStepArgs g;
   g.model = model; g.cfg = cfg; g.L = *layout; g.b = *bufs;
   if (inject) g.inj = *inject; else std::memset(&g.inj, 0, sizeof(g.inj));
-  g.actions = actions; g.step_counter = step_counter; g.mode = mode; g.stamps = nullptr; g.stats_next = nullptr;
+  g.actions = actions; g.step_counter = step_counter; g.mode = mode; g.stamps = nullptr; g.stats_next = nullptr; g.reset_mask = reset_mask;
   if (bufs->d_reset_stats && mode != 2) std::memset(bufs->d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS);
   if (cfg->env_kind == PF_KIND_POINTFOOT && model->nb == 9 && model->nd == 6 && model->nfeet == 2) {
     using K = PfKernel<9, 6, 2, PF_KIND_POINTFOOT>;

@@ -112,3 +112,131 @@ def test_emu_matches_oracle_full_physics_steps():
     np.testing.assert_allclose(b.obs, a.obs, atol=1e-4, rtol=0)
     np.testing.assert_allclose(b.rew, a.rew, atol=1e-4, rtol=0)
     np.testing.assert_allclose(b.state, a.state, atol=2e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------- collision geometry (a3 contract)
+# Vertical faces (legged_gym/utils/terrain.py:69-73, slope_treshold) and leg-leg self-collision
+# (pointfoot_rough_config.py:107) are part of the reference's physics contract.  Own model, parity unpinned; pinned
+# here by what the geometry has to do.
+def riser_sim(n=2, trimesh=True, height_raw=40):
+    """Frictionless ground at z = 0 for x < 5 m, a 0.2 m step up at x = 5 m; robots slide towards it at 1 m/s."""
+    import synth
+    cfg = common.make_cfg("rough", n, add_noise=False)
+    cfg.domain_rand.push_robots = False
+    cfg.terrain.static_friction = 0.0
+    if not trimesh:
+        cfg.terrain.mesh_type = "heightfield"      # no slope_treshold correction: the step is a 0.1 m wide ramp
+    hf = np.zeros((synth.TOT_ROWS, synth.TOT_COLS), np.int16)
+    hf[300:, :] = height_raw                        # grid line 300 = x 5.0 m
+    to = synth.synth_terrain_origins().astype(np.float32)
+    to[:, :, 2] = 0
+    sim = common.HostSim(cfg, n, hf=hf, terrain_origins=to)
+    root = sim.f("root", 13)
+    root[:, 0] = 4.80
+    root[:, 1] = np.linspace(3.0, 3.5, n)
+    root[:, 2] = 0.66
+    root[:, 7] = 1.0
+    sim.f("friction")[:] = 0.0
+    sim.f("env_origin", 3)[:] = root[:, :3] * [1, 1, 0]
+    return sim
+
+
+@pytest.mark.parametrize("backend", ["oracle", "emu"])
+def test_foot_pushed_against_a_riser_does_not_climb(backend):
+    sim = riser_sim()
+    n, nsph = sim.n, sim.model.nsph
+    assert sim.c.wall_threshold == pytest.approx(0.075)
+    touched = False
+    for t in range(14):        # until the body starts to topple over the blocked feet
+        sim.step(backend, np.zeros((n, 6), np.float32), t + 1)
+        fp = sim.f("feet_pos", 6).reshape(n, 2, 3)
+        assert (fp[:, :, 0] <= 5.0 - 0.03 + 0.012).all(), f"step {t}: a foot entered the riser: {fp[:, :, 0]}"      # 1 m/s impact: < 1 substep of travel
+        assert t < 2 or (fp[:, :, 2] <= 0.03 + 0.004).all(), f"step {t}: a foot climbed: {fp[:, :, 2]}"      # (the robot is set down during the first two steps)
+        face_bits = (sim.contact_set[:, -1, 0] >> np.uint64(nsph)) & np.uint64(3)      # face candidates of the two feet
+        touched = touched or bool((face_bits == 3).all())
+        assert not sim.reset.any()
+    assert touched, "the feet never reached the vertical face"
+    # the same field as a plain bilinear height field (mesh_type 'heightfield'): the feet stop at the foot of the ramp
+    ramp = riser_sim(trimesh=False)
+    assert ramp.c.wall_threshold == 0.0
+    for t in range(10):
+        ramp.step(backend, np.zeros((n, 6), np.float32), t + 1)
+    assert (ramp.f("feet_pos", 6).reshape(n, 2, 3)[:, :, 0] < 4.92).all()
+
+
+@pytest.mark.parametrize("backend", ["oracle", "emu"])
+def test_ground_next_to_a_riser_stays_low(backend):
+    """A robot set down inside the steep grid cell stands on the low ground (the trimesh's stretched low cell), not half
+    way up a ramp."""
+    sim = riser_sim()
+    n = sim.n
+    root = sim.f("root", 13)
+    root[:, 7] = 0.0
+    root[:, 0] = 4.95 + 0.065     # the feet hang 6.5 cm behind the base origin: they come down at x ~ 4.95, inside grid cell 299
+    sim.f("friction")[:] = 2.0     # mu = 0.5 * (2 + 0) = 1: no sliding
+    for t in range(8):
+        sim.step(backend, np.zeros((n, 6), np.float32), t + 1)
+    fp = sim.f("feet_pos", 6).reshape(n, 2, 3)
+    assert ((fp[:, :, 0] > 4.9) & (fp[:, :, 0] < 5.0 - 0.03 + 0.004)).all(), fp[:, :, 0]
+    np.testing.assert_allclose(fp[:, :, 2], 0.03, atol=0.004)
+
+
+def crossing_sim(self_collisions, n=2):
+    """Zero gravity, torque control: both abad joints are driven inwards with 20 N m."""
+    cfg = common.make_cfg("flat", n, control_type="T", add_noise=False)
+    cfg.domain_rand.push_robots = False
+    cfg.sim.gravity = [0., 0., 0.]
+    cfg.asset.self_collisions = 0 if self_collisions else 1
+    sim = common.HostSim(cfg, n)
+    sim.f("root", 13)[:, 2] = 50.0
+    act = np.zeros((n, 6), np.float32)
+    act[:, 0], act[:, 3] = -40.0, 40.0
+    return sim, act
+
+
+@pytest.mark.parametrize("backend", ["oracle", "emu"])
+def test_crossed_legs_are_pushed_apart(backend):
+    sim, act = crossing_sim(True)
+    n = sim.n
+    assert sim.model.npair == 16 and sim.c.self_collisions == 1
+    e0 = np.stack([energy(sim, i) for i in range(n)])
+    pressed = 0
+    for t in range(16):
+        sim.step(backend, act, t + 1)
+        fp = sim.f("feet_pos", 6).reshape(n, 2, 3)
+        # left foot stays on the left: the two 3 cm foot spheres may touch (centres 6 cm apart) but not pass
+        assert (fp[:, 0, 1] - fp[:, 1, 1] >= 0.06 - 0.004).all(), f"step {t}: feet interpenetrate {fp[:, :, 1]}"
+        cf = sim.f("contact_forces", 27).reshape(n, 9, 3)
+        pair_bits = sim.contact_set[:, -1, 0] >> np.uint64(2 * sim.model.nsph)
+        if (pair_bits != 0).all() and (np.abs(cf).sum(axis=(1, 2)) > 1.0).all():
+            pressed += 1
+            # action = reaction: the net contact forces of the two legs cancel
+            left, right = cf[:, 1:5].sum(axis=1), cf[:, 5:9].sum(axis=1)
+            np.testing.assert_allclose(left, -right, atol=1e-3 * np.abs(left).max() + 1e-4)
+            assert (left[:, 1] > 0).all(), "the left leg must be pushed to the left (+y)"
+        assert not np.isnan(sim.state).any()
+    assert pressed >= 4
+    e1 = np.stack([energy(sim, i) for i in range(n)])
+    np.testing.assert_allclose(e1[:, 2:5], e0[:, 2:5], atol=0.15)      # internal forces: linear momentum stays (integrator drift only)
+    # without self-collision the same drive swings the legs through each other
+    free, act = crossing_sim(False)
+    assert free.model.npair == 0 and free.c.self_collisions == 0
+    for t in range(8):
+        free.step(backend, act, t + 1)
+    fp = free.f("feet_pos", 6).reshape(n, 2, 3)
+    assert (fp[:, 0, 1] < fp[:, 1, 1]).all()
+
+
+def test_emu_matches_oracle_on_faces_and_self_contacts():
+    """HIP step program (host build) vs oracle on the two scenarios above: same contact sets, same motion."""
+    for make, acts in ((lambda: (riser_sim(4), None), 14), (lambda: crossing_sim(True, 4), 16)):
+        a, act = make()
+        b = a.clone()
+        if act is None:
+            act = np.zeros((a.n, 6), np.float32)
+        for t in range(acts):
+            a.step("oracle", act, t + 1)
+            b.step("emu", act, t + 1)
+            np.testing.assert_array_equal(a.contact_set, b.contact_set)
+            np.testing.assert_allclose(b.state, a.state, atol=5e-3, rtol=1e-3)
+            b.state[:] = a.state
