@@ -1,0 +1,31 @@
+/*
+ * pointfoot_hip_dev.h -- development / test hooks exported by libpointfoot_hip.so IN ADDITION to the drop-in boundary of
+ * pointfoot_hip.h.  Nothing here replaces a reference interface; a maintainer binding the library to the reference
+ * needs none of it.  Users: tests/test_gpu_ppo.py (GEMM family test), tools/gemm_bench.py, tools/step_stamps.py.
+ *
+ * Environment switches read by the library (diagnostics only; the defaults are the product path):
+ *   PF_PPO_PAIRED=0        actor / critic layers as separate launches on two streams instead of one paired launch
+ *   PF_PPO_FUSED_HEADS=0   unfused head / loss / head-backward kernels
+ *   PF_PPO_DUAL_STREAM=0   (with PAIRED=0) single stream
+ * They exist so that tests/test_gpu_ppo.py can hold every code path to the same oracle.
+ */
+#ifndef POINTFOOT_HIP_DEV_H
+#define POINTFOOT_HIP_DEV_H
+#include "pointfoot_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Run one GEMM of the PPO kernel family.  mode 0: C[M,N] = A[M,K] B[N,K]^T + bias, ELU;  1: C[M,N] = A[M,K] B[K,N] * ELU'(H);
+ * 2: C[M,N] = A[K,M]^T B[K,N] as split-K slabs into `ws`, reduced into C, column sums of A in C[M*N .. M*N+M).
+ * tile: -1 auto, 0: 128x128, 1: 128x64, 2: 64x64. */
+int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, float* C, const float* bias, const float* H,
+                 float* ws, int splits, int tile, void* stream);
+
+/* Diagnostic build (-DPF_STAMPS, tools/step_stamps.py) only: per-env phase cycle counters, 16 unsigned per env. */
+int pf_debug_set_stamps(PfEnv* env, unsigned* d_stamps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

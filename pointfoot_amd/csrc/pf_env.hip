@@ -7,6 +7,7 @@
 #include <string>
 
 #include "../../include/pointfoot_hip.h"
+#include "../../include/pointfoot_hip_dev.h"
 #include "pf_layout.h"
 #include "pf_step_kernel.h"
 
@@ -177,7 +178,7 @@ int pf_set_reset_stats_next(PfEnv* e, float* d_next) {
   return 0;
 }
 
-/* diagnostic build only: per-env phase cycle counters (PF_NSTAMP unsigned per env); not part of the boundary */
+/* development hook (include/pointfoot_hip_dev.h), diagnostic build only: per-env phase cycle counters (PF_NSTAMP unsigned per env) */
 int pf_debug_set_stamps(PfEnv* e, unsigned* d_stamps) { if (!e) return 1; e->d_stamps = d_stamps; return 0; }
 
 int pf_update_config(PfEnv* e, const PfConfig* cfg) {
@@ -211,28 +212,20 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
     g.stats_next = (e->stats_next && e->stats_next != e->bufs.d_reset_stats) ? e->stats_next : nullptr;
     e->stats_cleared = g.stats_next;
   }
-  // PF_STEP_RPW: robots per wavefront for the PointFoot instance (2: one per 32-lane half, 256-VGPR budget, default);
-  // PF_STEP_WAVES: register budget variant of the one-robot-per-wave kernel (waves per SIMD it is compiled for)
-  static const int rpw = [] { const char* v = getenv("PF_STEP_RPW"); return v ? atoi(v) : 2; }();
-  static const int variant = [] { const char* v = getenv("PF_STEP_WAVES"); return v ? atoi(v) : 4; }();
   const int N = e->cfg.num_envs;
-  // (two robots per wave were also tried for the quadruped instance and four PointFoot robots per wave: no gain --
-  // 0.843 vs 0.834 ms and 0.185 vs 0.172 ms at the time)
+  // Two kernel instances.  PointFoot: two robots per wavefront (one per 32-lane half), one wavefront per workgroup.
+  // LeggedRobot: one robot per wavefront, 8 wavefronts per workgroup sharing the read-only LDS block.  (Measured and
+  // dropped: one or four PointFoot robots per wave, 3 / 4 waves per SIMD register budgets -- all slower or spilling;
+  // two quadrupeds per wave: 0.843 vs 0.834 ms.)
   auto launch = [&](auto kern, size_t lds, int robots_per_block, int threads) {
     static bool raised = false;          // one kernel per env handle in practice; raising the limit again is harmless
     if (lds > 64 * 1024 && !raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
     hipLaunchKernelGGL(kern, dim3((N + robots_per_block - 1) / robots_per_block), dim3(threads), lds, s, e->d_model, e->d_cfg, g);
   };
   using KLR = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1>;
-  using KP1 = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 1>;
   using KP2 = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 2>;
-  static const int wpb_lr = [] { const char* v = getenv("PF_STEP_WPB_LR"); return v ? atoi(v) : 8; }();
-  if (e->instance == 1 && wpb_lr == 8) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8>, pf_lds_bytes<KLR, 1, 8>(), 8, 512);
-  else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 1>, pf_lds_bytes<KLR, 1, 1>(), 1, 64);
-  else if (rpw == 2) launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 1>, pf_lds_bytes<KP2, 2, 1>(), 2, 64);
-  else if (variant == 4) launch(pf_step_kernel<9, 6, 2, 4, PF_KIND_POINTFOOT, PF_KSPH, 1, 1>, pf_lds_bytes<KP1, 1, 1>(), 1, 64);
-  else if (variant == 3) launch(pf_step_kernel<9, 6, 2, 3, PF_KIND_POINTFOOT, PF_KSPH, 1, 1>, pf_lds_bytes<KP1, 1, 1>(), 1, 64);
-  else launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 1, 1>, pf_lds_bytes<KP1, 1, 1>(), 1, 64);
+  if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8>, pf_lds_bytes<KLR, 1, 8>(), 8, 512);
+  else launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 1>, pf_lds_bytes<KP2, 2, 1>(), 2, 64);
   PF_HIP_OK(hipGetLastError());
   return 0;
 }

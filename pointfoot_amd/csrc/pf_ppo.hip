@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/pointfoot_hip.h"
+#include "../../include/pointfoot_hip_dev.h"
 #include "pf_gemm.h"
 
 void pf_set_error(const std::string& s);
@@ -1065,7 +1066,7 @@ static void ppo_join(PpoAlg* a, hipStream_t s, hipStream_t other) {
 
 extern "C" {
 
-/* Development / test hook (not part of the drop-in boundary, hence not in pointfoot_hip.h): run one GEMM of the PPO
+/* Development / test hook (not part of the drop-in boundary: declared in include/pointfoot_hip_dev.h): run one GEMM of the PPO
  * kernel family.  mode 0: C[M,N] = A[M,K] B[N,K]^T + bias, ELU; 1: C[M,N] = A[M,K] B[K,N] * ELU'(H); 2: C[M,N] = A[K,M]^T B[K,N]
  * (split-K slabs into `ws`, then reduced into C with the column sums of A in C[M*N .. M*N+M)).  tile: -1 auto, 0/1/2. */
 int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, float* Cm, const float* bias, const float* H,

@@ -90,9 +90,13 @@ class HipEnv:
         self.num_obs = cfg.env.num_propriceptive_obs if self.KIND == _abi.PF_KIND_POINTFOOT else cfg.env.num_observations
         self.num_privileged_obs = cfg.env.num_privileged_obs
         self.num_actions = cfg.env.num_actions
-        # multi-GPU sharding: rank r owns global envs [r*N, (r+1)*N)  
-        self.rank = int(os.environ.get("RANK", "0")) if getattr(cfg, "shard_envs", True) else 0
-        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if getattr(cfg, "shard_envs", True) else 1
+        # multi-GPU sharding: rank r owns global envs [r*N, (r+1)*N)  (SURVEY §8e).  Rank / world size come from the process
+        # group -- the same source PPO and the runner use -- so env shards and the gradient all-reduce cannot disagree.
+        from pointfoot_amd.rsl_rl import dp
+        self.rank, self.world_size = dp.world() if getattr(cfg, "shard_envs", True) else (0, 1)
+        if getattr(cfg, "shard_envs", True) and self.world_size == 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call pointfoot_amd.rsl_rl.dp.init_from_env() "
+                               "before creating the env (or set cfg.shard_envs = False for independent replicas)")
         self.extras = {}
         self.viewer = None
         self.enable_viewer_sync = True
@@ -104,9 +108,15 @@ class HipEnv:
 
     # ------------------------------------------------------------------ reference-compatible hooks
     def update_frictions(self, fric, env_handle=0, actor_handle=0):
-        """reference :103-108 sets DOF friction via gym; here: the env's shape friction coefficient."""
-        v = float(np.mean(np.asarray(fric, dtype=np.float64)))
-        self._state[int(env_handle), self._L.friction] = v
+        """reference :103-108: `dof_props["friction"][i] = fric[i]` for every DOF of one actor -- joint (Coulomb)
+        friction.  Kept per env and DOF in `joint_friction` (N, num_dof); the physics substep opposes each joint's
+        motion with that torque (regularised below 0.1 rad/s)."""
+        if self.joint_friction is None:
+            self.joint_friction = torch.zeros(self.num_envs, self.num_dof, device=self.device, dtype=torch.float)
+            self._bufs.d_joint_friction = _native.ptr(self.joint_friction)
+            _abi.check(self._lib.pf_bind_buffers(self._h, C.byref(self._bufs)), self._lib)
+        f = torch.as_tensor(np.asarray(fric, dtype=np.float32).reshape(-1)[:self.num_dof], device=self.device)
+        self.joint_friction[int(env_handle), :f.numel()] = f
 
     def update_added_mass_and_base_com(self, added_mass, added_com, env_handle=0, actor_handle=0):
         """reference :110-121"""
@@ -158,6 +168,7 @@ class HipEnv:
         self.common_step_counter += 1
         self._next_stats_slot()
         _abi.check(self._lib.pf_step(self._h, a.data_ptr(), self.common_step_counter, None, self._stream()), self._lib)
+        self._maybe_update_command_curriculum()
         self._fill_extras()
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
@@ -177,9 +188,42 @@ class HipEnv:
             return
         if len(env_ids) == self.num_envs:
             _abi.check(self._lib.pf_reset_all(self._h, self.common_step_counter, None, self._stream()), self._lib)
-            self._fill_extras()
+        else:
+            # a subset (scripted single-env resets, scripts/simulate_trajectory.py:72-97): same launch, masked on the device
+            mask = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+            mask[torch.as_tensor(env_ids, device=self.device, dtype=torch.long)] = 1
+            self._next_stats_slot()
+            _abi.check(self._lib.pf_reset_idx(self._h, mask.data_ptr(), self.common_step_counter, None, self._stream()), self._lib)
+        self._fill_extras()
+
+    def update_command_curriculum(self, env_ids=None):
+        """reference :638-650 (legged_robot.py:303-315): widen the lin_vel_x command range by 0.5 m/s when the mean
+        tracking reward of the envs that were just reset exceeds 80 % of its maximum.  `env_ids` is implied: the mean
+        is taken from the step's reset statistics (sum of episode_sums over the reset envs / their count)."""
+        if "tracking_lin_vel" not in self._sum_names:
             return
-        raise NotImplementedError("host-side partial reset_idx: resets are taken by the step kernel (masked, in place)")
+        i = self._sum_names.index("tracking_lin_vel")
+        stats = self._reset_stats
+        cnt = float(stats[_abi.PF_MAX_REWARDS].item())        # host sync, once per max_episode_length steps
+        if cnt <= 0:
+            return
+        mean_sum = float(stats[i].item()) / cnt
+        if mean_sum / self.max_episode_length > 0.8 * self.reward_scales["tracking_lin_vel"]:
+            r = self.command_ranges["lin_vel_x"]
+            mc = self.cfg.commands.max_curriculum
+            r[0] = float(np.clip(r[0] - 0.5, -mc, 0.))
+            r[1] = float(np.clip(r[1] + 0.5, 0., mc))
+            c = self._cfg_c
+            c.cmd_lo[0], c.cmd_hi[0] = r[0], r[1]               # LeggedRobot resamples commands from these on the device
+            _abi.check(self._lib.pf_update_config(self._h, C.byref(c)), self._lib)
+
+    def _maybe_update_command_curriculum(self):
+        """reference :264-266: only on steps where common_step_counter % max_episode_length == 0 (the maximum command is
+        common to all envs).  In-kernel resets of that step have already drawn from the old range: the new range
+        applies from the next resampling on (one step later than the reference)."""
+        if self.cfg.commands.curriculum and self.init_done and \
+                self.common_step_counter % int(self.max_episode_length) == 0:
+            self.update_command_curriculum()
 
     def compute_observations(self):
         _abi.check(self._lib.pf_compute_observations(self._h, self.common_step_counter, None, self._stream()), self._lib)
@@ -195,13 +239,32 @@ class HipEnv:
         nxt = self._stats_ring[(self._stats_slot + 1) % self._stats_ring.shape[0]]
         _abi.check(self._lib.pf_set_reset_stats_next(self._h, nxt.data_ptr()), self._lib)
 
+    def bind_contact_set(self):
+        """Diagnostic (parity tests): have the step kernel export its discrete decisions per substep -- active contact
+        candidates, joint-limit rows, grid cells (PfBuffers.d_contact_set) -- into the returned (N, decimation, 3) tensor."""
+        self.contact_set = torch.zeros(self.num_envs, self.cfg.control.decimation, 3, dtype=torch.int64, device=self.device)
+        self._bufs.d_contact_set = _native.ptr(self.contact_set)
+        _abi.check(self._lib.pf_bind_buffers(self._h, C.byref(self._bufs)), self._lib)
+        return self.contact_set
+
+    def ensure_stats_ring(self, num_steps):
+        """The lazily-read per-step statistics must survive until the runner logs the iteration: the ring needs more
+        slots than steps between two logs (the step kernel clears the slot after the one it fills)."""
+        need = int(num_steps) + 2
+        if self._stats_ring.shape[0] < need:
+            self._stats_ring = torch.zeros(need, _abi.PF_STATS_FLOATS, device=self.device, dtype=torch.float)
+            self._stats_slot = 0
+            self._reset_stats = self._stats_ring[0]
+
     def _fill_extras(self):
         # reference :276-288
         stats, names, T = self._reset_stats, self._sum_names, self.max_episode_length_s
         curriculum, levels = self.cfg.terrain.curriculum, self.terrain_levels
 
         def fill():
-            cnt = stats[_abi.PF_MAX_REWARDS].clamp(min=1.0)
+            # mean over the envs reset this step; NaN when none was (the reference sends no fresh 'episode' entry on such
+            # steps): the runner's per-iteration mean skips NaNs, so empty steps do not dilute the logged values
+            cnt = stats[_abi.PF_MAX_REWARDS]
             vals = stats[:len(names)] / cnt / T
             ep = {'rew_' + k: vals[i] for i, k in enumerate(names)}
             if curriculum:
@@ -371,7 +434,8 @@ class HipEnv:
         self._episode_length_buf = torch.zeros(N, device=dev, dtype=torch.long)
         H = self._cfg_c.num_height_points
         self.measured_heights = torch.zeros(N, H, device=dev, dtype=torch.float) if H else 0
-        self._stats_ring = torch.zeros(64, _abi.PF_STATS_FLOATS, device=dev, dtype=torch.float)
+        self._stats_ring = torch.zeros(64, _abi.PF_STATS_FLOATS, device=dev, dtype=torch.float)      # see ensure_stats_ring
+        self.joint_friction = None       # (N, num_dof) after the first update_frictions call
         self._stats_slot = 0
         self._reset_stats = self._stats_ring[0]
         self.common_step_counter = 0

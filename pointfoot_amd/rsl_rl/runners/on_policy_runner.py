@@ -39,6 +39,8 @@ class OnPolicyRunner:
         self.save_interval = self.cfg["save_interval"]
         self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs], [self.env.num_privileged_obs],
                               [self.env.num_actions])
+        if hasattr(self.env, "ensure_stats_ring"):
+            self.env.ensure_stats_ring(self.num_steps_per_env)     # lazily-read episode statistics must outlive one iteration
         self.log_dir = log_dir
         self.writer = None
         self.tot_timesteps = 0
@@ -118,7 +120,8 @@ class OnPolicyRunner:
         if locs['ep_infos']:
             for key in locs['ep_infos'][0]:
                 vals = [ep[key] for ep in locs['ep_infos'] if key in ep]
-                value = float(torch.stack([torch.as_tensor(v, dtype=torch.float).reshape(()).to(self.device) for v in vals]).mean())
+                # steps on which no env was reset carry NaN (no fresh episode entry in the reference): mean over the others
+                value = float(torch.nanmean(torch.stack([torch.as_tensor(v, dtype=torch.float).reshape(()).to(self.device) for v in vals])))
                 if self.writer:
                     self.writer.add_scalar('Episode/' + key, value, locs['it'])
                 ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
@@ -164,7 +167,7 @@ class OnPolicyRunner:
                     'infos': infos}, path)
 
     def load(self, path, load_optimizer=True):
-        loaded = torch.load(path, map_location=self.device, weights_only=False)
+        loaded = torch.load(path, map_location=self.device, weights_only=True)      # tensors and plain containers only: nothing from the file is executed
         self.alg.actor_critic.load_state_dict(loaded['model_state_dict'])      # copies into the flat-buffer views
         if load_optimizer:
             self.alg.load_optimizer_state_dict(loaded['optimizer_state_dict'])

@@ -6,8 +6,11 @@ they are restated from that module's documented behaviour
 no reference artefact exists for them.  numpy's global RNG is used exactly where the reference does,
 so `set_seed` makes the map reproducible.
 
-The height field is the collision surface of the HIP step kernel (sphere-vs-heightfield); the
-reference's trimesh conversion (`slope_treshold`) is not needed for that and is not built.
+The height field is what the HIP step kernel collides against.  For mesh_type 'trimesh' the reference converts it
+to a triangle mesh whose steep steps become vertical faces (terrain.py:69-73, `slope_treshold`); the kernel
+evaluates that same correction per grid cell straight from the height field (csrc/pf_step_kernel.h,
+`terrain_query`), so no mesh is needed at run time.  `Terrain.vertices` / `.triangles` are still provided, built on
+first access by `convert_heightfield_to_trimesh` below, for callers that export or inspect the mesh.
 """
 import numpy as np
 
@@ -136,7 +139,55 @@ def pit_terrain(terrain, depth, platform_size=1.):             # reference terra
     terrain.height_field_raw[x1:x2, y1:y2] = -d
 
 
+def convert_heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_scale, slope_threshold=None):
+    """Grid -> (vertices float32 (R*C, 3), triangles uint32 (2 (R-1)(C-1), 3)); stands in for the function of that name in
+    isaacgym.terrain_utils (call site terrain.py:70; parity unpinned).  Where the height difference between two grid
+    neighbours exceeds slope_threshold * horizontal_scale / vertical_scale, the LOW vertex is slid one grid step towards
+    the high one (x, y, or -- where neither applies -- diagonally), so the step becomes a vertical face on the high
+    vertex's grid line and the ground next to it keeps the low height."""
+    hf = np.asarray(height_field_raw)
+    R, Cn = hf.shape
+    yy, xx = np.meshgrid(np.linspace(0, (Cn - 1) * horizontal_scale, Cn), np.linspace(0, (R - 1) * horizontal_scale, R))
+    if slope_threshold is not None:
+        thr = slope_threshold * horizontal_scale / vertical_scale
+        h = hf.astype(np.int64)
+        mx, my, mc = np.zeros((R, Cn)), np.zeros((R, Cn)), np.zeros((R, Cn))
+        dx, dy, dd = h[1:, :] - h[:-1, :], h[:, 1:] - h[:, :-1], h[1:, 1:] - h[:-1, :-1]
+        mx[:-1, :] += dx > thr            # low vertex before a rise: forward
+        mx[1:, :] -= -dx > thr            # low vertex after a drop: back
+        my[:, :-1] += dy > thr
+        my[:, 1:] -= -dy > thr
+        mc[:-1, :-1] += dd > thr
+        mc[1:, 1:] -= -dd > thr
+        xx = xx + (mx + mc * (mx == 0)) * horizontal_scale
+        yy = yy + (my + mc * (my == 0)) * horizontal_scale
+    vertices = np.stack([xx.ravel(), yy.ravel(), hf.ravel() * vertical_scale], axis=1).astype(np.float32)
+    i0 = (np.arange(R - 1)[:, None] * Cn + np.arange(Cn - 1)[None, :]).ravel()
+    tri = np.empty((2 * i0.size, 3), dtype=np.uint32)
+    tri[0::2] = np.stack([i0, i0 + Cn + 1, i0 + 1], axis=1)
+    tri[1::2] = np.stack([i0, i0 + Cn, i0 + Cn + 1], axis=1)
+    return vertices, tri
+
+
 class Terrain:
+    @property
+    def vertices(self):
+        self._ensure_mesh()
+        return self._mesh[0]
+
+    @property
+    def triangles(self):
+        self._ensure_mesh()
+        return self._mesh[1]
+
+    def _ensure_mesh(self):
+        """reference terrain.py:68-73 builds the mesh eagerly for mesh_type 'trimesh' (2.7 M vertices); here on first use"""
+        if getattr(self, "_mesh", None) is None:
+            if self.type != "trimesh":
+                raise AttributeError("vertices / triangles exist for mesh_type 'trimesh' only")
+            self._mesh = convert_heightfield_to_trimesh(self.height_field_raw, self.cfg.horizontal_scale, self.cfg.vertical_scale,
+                                                        self.cfg.slope_treshold)
+
     def __init__(self, cfg, num_robots) -> None:
         self.cfg = cfg
         self.num_robots = num_robots

@@ -669,10 +669,59 @@ def misc_vectors():
     return out
 
 
+def terrain_grid_vectors(seed=1):
+    """Pins the reference's OWN curriculum-grid logic (legged_gym/utils/terrain.py:38-164: curiculum(), make_terrain(),
+    add_terrain_to_map(), origin rule, borders) for the pointfoot_rough terrain config.  The sub-terrain generators
+    belong to the closed isaacgym.terrain_utils package; THIS REPO's restatements (pointfoot_amd/utils/terrain.py) are
+    plugged into the stub module, wrapped so that every call the reference makes is logged (tile, generator, arguments).
+    The fixture therefore fixes which generator the reference calls for which tile with which parameters, in which
+    order (= numpy RNG consumption order), where it pastes the tile and how it derives env_origins -- not the
+    generators' own arithmetic, which stays parity-unpinned."""
+    import hashlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from pointfoot_amd.utils import terrain as mine
+    from pointfoot_amd.envs.pointfoot.mixed_terrain.pointfoot_rough_config import PointFootRoughCfg
+    tu = sys.modules["isaacgym.terrain_utils"]
+    calls = []
+
+    def wrap(name):
+        fn = getattr(mine, name)
+
+        def logged(terrain, *a, **kw):
+            calls.append((name, tuple(float(v) for v in a), tuple(sorted((k, float(v)) for k, v in kw.items()))))
+            return fn(terrain, *a, **kw)
+        return logged
+    tu.SubTerrain = mine.SubTerrain
+    for name in ("pyramid_sloped_terrain", "random_uniform_terrain", "pyramid_stairs_terrain", "discrete_obstacles_terrain",
+                 "stepping_stones_terrain"):
+        setattr(tu, name, wrap(name))
+    tu.convert_heightfield_to_trimesh = lambda hf, hs, vs, thr: (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
+    from legged_gym.envs.pointfoot.point_foot import PointFoot  # noqa: F401  (resolves the reference's envs <-> utils import cycle)
+    from legged_gym.utils.terrain import Terrain as RefTerrain
+    cfg = PointFootRoughCfg.terrain()          # same values as the reference's pointfoot_rough_config.py:14-44
+    np.random.seed(seed)
+    t = RefTerrain(cfg, 4096)
+    hf = np.ascontiguousarray(t.height_field_raw)
+    names = sorted({c[0] for c in calls})
+    out = {"seed": np.int64(seed), "shape": np.array(hf.shape), "sha256": np.frombuffer(hashlib.sha256(hf.tobytes()).digest(), np.uint8),
+           "env_origins": t.env_origins.copy(), "coarse": hf[::13, ::17].copy(),
+           "tile_max": np.array([[hf[t.border + i * t.length_per_env_pixels:t.border + (i + 1) * t.length_per_env_pixels,
+                                     t.border + j * t.width_per_env_pixels:t.border + (j + 1) * t.width_per_env_pixels].max()
+                                  for j in range(cfg.num_cols)] for i in range(cfg.num_rows)]),
+           "call_names": np.array(names), "call_gen": np.array([names.index(c[0]) for c in calls]),
+           "call_args": np.array([list(c[1]) + [v for _, v in c[2]] + [np.nan] * (8 - len(c[1]) - len(c[2])) for c in calls]),
+           "border_px": np.int64(t.border), "tot_rows": np.int64(t.tot_rows), "tot_cols": np.int64(t.tot_cols)}
+    return out
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
     import legged_gym  # noqa: F401
+    if len(sys.argv) > 1 and sys.argv[1] == "terrain":        # only the terrain-grid fixture
+        np.savez_compressed(os.path.join(HERE, "terrain_grid.npz"), **terrain_grid_vectors())
+        print("wrote terrain_grid.npz")
+        return
     jobs = [("flat", 64, 6, 1, "P", True), ("rough", 64, 6, 2, "P", True),
             ("flat", 16, 2, 3, "V", False), ("flat", 16, 2, 4, "T", False)]
     for task, n, steps, seed, ct, noise in jobs:
@@ -685,6 +734,8 @@ def main():
     fn = os.path.join(HERE, "lr_anymal_c_rough_n32.npz")
     np.savez_compressed(fn, **out)
     print("wrote", fn, os.path.getsize(fn), "bytes; rewards:", list(out["reward_names"]))
+    np.savez_compressed(os.path.join(HERE, "terrain_grid.npz"), **terrain_grid_vectors())
+    print("wrote terrain_grid.npz")
 
 
 if __name__ == "__main__":

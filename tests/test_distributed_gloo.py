@@ -88,7 +88,7 @@ def test_data_parallel_gradient_matches_single_process(tmp_path):
     out = str(tmp_path / "dp.pt")
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
-    r = torch.load(out, weights_only=False)
+    r = torch.load(out, weights_only=True)
     ac = ppo_ref.RefActorCritic(27, 27, 6, [32, 16], [32, 16])
     ac.load_flat(r["flat"])
     loss, kl, _, _ = ppo_ref.minibatch_loss(ac, r["data"], 0.2, 1.0, 0.01)      # the concatenated global batch

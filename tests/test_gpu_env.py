@@ -86,6 +86,11 @@ def test_hip_full_step_matches_oracle(task):
     cf = slice(L.contact_forces, L.contact_forces + 27)
     tq = slice(L.torques, L.torques + 6)
     keep_cols = np.ones(L.rec_floats, bool); keep_cols[cf] = False; keep_cols[tq] = False
+    # velocities: the obs tolerance (1e-4 on dof_vel * 0.05, ang_vel * 0.25) is 2e-3 rad/s on the raw state
+    vel_cols = np.zeros(L.rec_floats, bool)
+    for off, w in ((L.root + 7, 6), (L.dof_vel, 6), (L.last_dof_vel, 6), (L.last_root_vel, 6), (L.base_lin_vel, 3), (L.base_ang_vel, 3)):
+        vel_cols[off:off + w] = True
+    keep_cols &= ~vel_cols
     for t in range(30):
         act = rs.normal(0, 0.7, (n, 6)).astype(np.float32)
         # both sides start this step from the oracle's state
@@ -105,6 +110,7 @@ def test_hip_full_step_matches_oracle(task):
         else:
             np.testing.assert_allclose(sim.priv[m], ref.priv[m], atol=1e-4, rtol=0)
         np.testing.assert_allclose(sim.state[m][:, keep_cols], ref.state[m][:, keep_cols], atol=5e-4, rtol=1e-3, err_msg=f"step {t} state")
+        np.testing.assert_allclose(sim.state[m][:, vel_cols], ref.state[m][:, vel_cols], atol=2e-3, rtol=1e-3, err_msg=f"step {t} velocities")
         # contact force = impulse / 5 ms: float32 reassociation in the solver is amplified 200x
         np.testing.assert_allclose(sim.state[m][:, cf], ref.state[m][:, cf], atol=0.5, rtol=2e-2, err_msg=f"step {t} contact forces")
         # the last substep's PD torque = -Kd (1.5) x a joint velocity that is itself only good to 2e-3 rad/s (obs tolerance / 0.05)

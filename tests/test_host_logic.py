@@ -19,6 +19,13 @@ def test_library_exports_every_declared_symbol_and_abi_sizes_match():
     for name in declared:
         assert hasattr(lib, name), f"libpointfoot_hip.so does not export {name}"
     _abi.load()      # checks pf_abi_sizes against the ctypes mirror
+    # ... and nothing else: every pf_* / ppo_* symbol the library exports is declared in one of the two headers
+    import subprocess
+    dev = re.sub(r"/\*.*?\*/", "", open(os.path.join(common.ROOT, "include", "pointfoot_hip_dev.h")).read(), flags=re.S)
+    dev_declared = set(re.findall(r"\b((?:pf|ppo)_[a-z_0-9]+)\s*\(", dev))
+    nm = subprocess.run(["nm", "-D", "--defined-only", _abi.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if re.match(r"^[0-9a-f]+ T (pf|ppo)_", ln)}
+    assert exported == declared | dev_declared, exported ^ (declared | dev_declared)
 
 
 def test_pf_layout_host_only_and_error_reporting():
@@ -104,3 +111,54 @@ def test_legged_robot_cfg_defaults_kept():
     assert c.env.num_envs == 4096 and c.env.num_observations == 235 and len(c.terrain.measured_points_x) == 17
     assert c.rewards.only_positive_rewards and c.domain_rand.push_interval_s == 15 and c.sim.physx.solver_type == 1
     assert p.algorithm.num_learning_epochs == 5 and p.runner.max_iterations == 1500 and p.policy.activation == "elu"
+
+
+def test_terrain_grid_logic_matches_reference_fixture(monkeypatch):
+    """a15: `pointfoot_amd.utils.terrain.Terrain` against the reference's own `Terrain` (legged_gym/utils/terrain.py:38-164)
+    run on the same generators (tests/golden/make_golden.py::terrain_grid_vectors): identical generator call sequence
+    (tile order, generator choice, slope / step height / obstacle height per tile = curiculum() + make_terrain()),
+    identical pasted field (sha256 over 1300 x 2100 int16) and identical env_origins (add_terrain_to_map's origin rule)."""
+    import hashlib
+    from pointfoot_amd.utils import terrain as mine
+    from pointfoot_amd.envs.pointfoot.mixed_terrain.pointfoot_rough_config import PointFootRoughCfg
+    g = common.load_golden("terrain_grid")
+    calls = []
+    for name in ("pyramid_sloped_terrain", "random_uniform_terrain", "pyramid_stairs_terrain", "discrete_obstacles_terrain",
+                 "stepping_stones_terrain"):
+        fn = getattr(mine, name)
+
+        def logged(terrain, *a, _fn=fn, _name=name, **kw):
+            calls.append((_name, tuple(float(v) for v in a), tuple(sorted((k, float(v)) for k, v in kw.items()))))
+            return _fn(terrain, *a, **kw)
+        monkeypatch.setattr(mine, name, logged)
+    np.random.seed(int(g["seed"]))
+    t = mine.Terrain(PointFootRoughCfg.terrain(), 4096)
+    hf = np.ascontiguousarray(t.height_field_raw)
+    assert tuple(g["shape"]) == hf.shape == (int(g["tot_rows"]), int(g["tot_cols"])) and t.border == int(g["border_px"])
+    names = list(g["call_names"])
+    assert [names.index(c[0]) for c in calls] == list(g["call_gen"]), "generator sequence differs from the reference's make_terrain"
+    args = np.array([list(c[1]) + [v for _, v in c[2]] + [np.nan] * (8 - len(c[1]) - len(c[2])) for c in calls])
+    np.testing.assert_array_equal(args, g["call_args"])
+    np.testing.assert_array_equal(hf[::13, ::17], g["coarse"])
+    assert hashlib.sha256(hf.tobytes()).digest() == bytes(g["sha256"])
+    np.testing.assert_array_equal(t.env_origins, g["env_origins"])
+
+
+def test_trimesh_conversion_makes_vertical_faces():
+    """f1: the mesh restatement (isaacgym.terrain_utils.convert_heightfield_to_trimesh, call site terrain.py:69-73;
+    parity unpinned) turns a step steeper than slope_treshold into a vertical face on the high vertex's grid line and
+    leaves a gentle slope alone -- the geometry the step kernel's `terrain_query` evaluates per cell."""
+    from pointfoot_amd.utils.terrain import convert_heightfield_to_trimesh
+    hf = np.zeros((8, 6), np.int16)
+    hf[4:, :] = 40            # 0.2 m step between rows 3 and 4 (slope 2.0 > 0.75)
+    hf[:, 4:] += 10           # 0.05 m step between columns 3 and 4 (slope 0.5: stays a ramp)
+    v, t = convert_heightfield_to_trimesh(hf, 0.1, 0.005, 0.75)
+    v = v.reshape(8, 6, 3)
+    assert t.shape == (2 * 7 * 5, 3) and t.max() == 8 * 6 - 1
+    np.testing.assert_allclose(v[3, :, 0], 0.4, atol=1e-6)        # low row 3 slid under high row 4: face at x = 0.4
+    np.testing.assert_allclose(v[4, :, 0], 0.4, atol=1e-6)
+    np.testing.assert_allclose(v[2, :, 0], 0.2, atol=1e-6)        # its neighbour stays: the low cell is stretched
+    np.testing.assert_allclose(np.delete(v[:, 3, 1], 3), 0.3, atol=1e-6)   # gentle step: untouched (row 3 also slides diagonally: 0.25 m corner rise)
+    np.testing.assert_allclose(v[:, :, 2], hf * 0.005, atol=1e-7)
+    v0, _ = convert_heightfield_to_trimesh(hf, 0.1, 0.005, None)
+    np.testing.assert_allclose(v0.reshape(8, 6, 3)[3, :, 0], 0.3, atol=1e-6)

@@ -1,5 +1,5 @@
 """Micro-benchmark of the fused env-step kernel alone (pointfoot_rough, N envs, random actions):
-   PF_STEP_WAVES={2,3,4} python tools/step_bench.py [N] [launches]"""
+   python tools/step_bench.py [N] [launches] [task]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,7 @@ args = get_args(["--task", task, "--headless", "--num_envs", str(N)])
 env, _ = task_registry.make_env(task, args=args)
 env.reset()
 g = torch.Generator(device="cuda:0").manual_seed(0)
-acts = [torch.randn(N, 6, device="cuda:0", generator=g) * 0.5 for _ in range(8)]
+acts = [torch.randn(N, env.num_actions, device="cuda:0", generator=g) * 0.5 for _ in range(8)]
 for i in range(30):
     env.step(acts[i % 8])
 torch.cuda.synchronize()
@@ -23,5 +23,5 @@ for i in range(K):
     env.step(acts[i % 8])
 e.record(); torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / K * 1e6
-print(f"PF_STEP_WAVES={os.environ.get('PF_STEP_WAVES','2')} N={N} {task}: {s.elapsed_time(e) / K * 1e3:.1f} us/launch (event), {wall:.1f} us wall; "
+print(f"N={N} {task}: {s.elapsed_time(e) / K * 1e3:.1f} us/launch (event), {wall:.1f} us wall; "
       f"{N / (s.elapsed_time(e) / K * 1e-3) / 1e6:.2f} M env-steps/s kernel-only; resets/step ~{float(env.reset_buf.float().mean()) * N:.0f}")
