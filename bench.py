@@ -28,9 +28,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
 STEP_BYTES_PER_ENV = 2072      # algorithmic bytes per env-step, pointfoot_rough
 PPO_MFLOP_PER_ENV_STEP = 13.4  # 0.84 rollout + 12.5 update
-# HBM bytes per step-kernel launch from rocprofv3 PMC passes (profiles/r1_step_kernel_hbm_pmc.md; N=4096 rough):
-# FETCH_SIZE 8104 KB (x2: gfx950 half-count correction) + WRITE_SIZE 24345 KB (15 MB of it scratch write-back)
-STEP_TRAFFIC_BYTES_N4096_ROUGH = 2 * 3878.0 * 1024 + 7545.0 * 1024     # profiles/r1_step_kernel_hbm_pmc.md (FETCH_SIZE x2 upper bound + WRITE_SIZE)
+# HBM bytes per step-kernel launch come from the committed rocprofv3 PMC summary of THIS kernel (tools/pmc_traffic.py
+# writes it from separate --pmc passes, with the guide's gfx950 corrections); used only when kernel, task and env count match.
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r2_step_kernel_hbm_pmc.json")
+
+
+def step_traffic(kernel_prefix, task, num_envs):
+    try:
+        with open(TRAFFIC_PROFILE) as f:
+            p = json.load(f)
+        if p["kernel"].startswith(kernel_prefix) and p["task"] == task and int(p["num_envs"]) == num_envs:
+            return float(p["traffic_bytes_per_launch"]), os.path.relpath(TRAFFIC_PROFILE, ROOT)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
 
 
 def parse():
@@ -111,7 +122,18 @@ def cpu_baseline(task, num_envs, threads):
     return dict(value=num_envs * T / total, unit="env-steps/s", cores=threads, kind="port",
                 sample=f"1 PPO iteration = {num_envs} envs x {T} steps (oracle C++ env step with OpenMP: {t_collect:.2f}s; "
                        f"torch-CPU PPO 5x4 minibatches: {total - t_collect:.2f}s); restatement CPU baseline, reference binary unavailable",
-                host_cpus=os.cpu_count())
+                host_cpus=os.cpu_count(), cpu_model=cpu_model())
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -182,6 +204,15 @@ def main():
     step_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_pairs]))            # one fused env-step launch
     upd_ms = float(np.mean([s.elapsed_time(e) for s, e in up_pairs]))
     finite = bool(torch.isfinite(runner.alg.params).all().item()) and bool(torch.isfinite(env.rew_buf).all().item())
+    lockstep = None
+    if world > 1:
+        # every rank must hold the same policy and have taken the same learning-rate decisions: compare a checksum of the
+        # flat parameter buffer (as exact integers: the float32 bit patterns summed in int64) and the LR scalar across ranks
+        alg = runner.alg
+        chk = torch.stack([alg.params.view(torch.int32).to(torch.int64).sum(), alg.scalars[0:1].view(torch.int32).to(torch.int64)[0]])
+        allchk = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allchk, chk)
+        lockstep = all(bool(torch.equal(c, allchk[0])) for c in allchk)
     if rank == 0:
         rough = "rough" in a.task
         anymal = a.task.startswith("anymal")
@@ -198,6 +229,7 @@ def main():
         headline = a.task == "pointfoot_rough" and a.num_envs == NUM_ENVS
         dims = lambda d: "-".join(str(v) for v in d)
         kern = "pf_step_kernel<17,12,4,LeggedRobot>" if anymal else "pf_step_kernel<9,6,2,PointFoot>"
+        traffic, traffic_src = step_traffic("pf_step_kernel<17" if anymal else "pf_step_kernel<9", a.task, a.num_envs)
         out = {
             "metric": "env-steps/sec (whole node), pointfoot_rough 4096 envs/GPU" if headline else f"env-steps/sec (whole node), {a.task} {a.num_envs} envs/GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
@@ -210,9 +242,10 @@ def main():
                                    + (", ANYdrive actuator-network LSTM in the step kernel" if anymal else ""),
                        "parallelism": f"dp{n_gpus} (env shards, RCCL gradient all-reduce)" if n_gpus > 1 else "single GPU",
                        "finite": finite},
+            "ranks_in_lockstep": lockstep,
             "roofline": {"kernel": kern + " (fused env step)", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": STEP_TRAFFIC_BYTES_N4096_ROUGH if headline else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": step_ms, "bytes_per_launch": bytes_per_env * a.num_envs,
                          "note": "latency/occupancy-bound by construction (SURVEY §8d honesty note); launch_ms from HIP events on the launch stream"},
             "roofline_ppo": {"kernel": "pf_gemm_kernel (fp32 MFMA) inside the PPO update", "bound": "mfma", "achieved": ach_tf,
@@ -223,7 +256,12 @@ def main():
         }
         if n_gpus == 1 and not a.no_cpu_baseline and not anymal:
             try:
-                out["cpu_baseline"] = cpu_baseline(a.task, a.num_envs, min(10, os.cpu_count() or 1))
+                # once at the reference's physx.num_threads (10, pointfoot_rough_config.py:203) and once on
+                # all host cores; one PPO iteration each (a bounded sample: a few seconds of CPU work per run)
+                ncpu = os.cpu_count() or 1
+                out["cpu_baseline"] = cpu_baseline(a.task, a.num_envs, min(10, ncpu))
+                if ncpu > 10:
+                    out["cpu_baseline"]["all_cores"] = cpu_baseline(a.task, a.num_envs, ncpu)
             except Exception as ex:      # the baseline is informational; never lose the GPU measurement over it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
         print(json.dumps(out), flush=True)

@@ -1164,7 +1164,10 @@ struct PfKernel {
       S[LC::root + i] = v;
     }
     if constexpr (LR) resample_commands(sh, c, L, inj, env, step, L.r_cmd_reset);     // legged_robot.py:168
-    PF_LANES(f, NF) {       // :290-299
+    // :290-299 (inside a step the two `last_*` rows are overwritten again at :225-227; a host reset_idx leaves them zero)
+    PF_LANES(k, c.num_actions) S[LC::last_actions + k] = 0.0f;
+    PF_LANES(k, ND) S[LC::last_dof_vel + k] = 0.0f;
+    PF_LANES(f, NF) {
       S[LC::feet_air_time + f] = 0.0f; S[LC::last_feet_air_time + f] = 0.0f;
       S[LC::cur_max_feet_height + f] = 0.0f; S[LC::last_max_feet_height + f] = 0.0f;
     }

@@ -201,3 +201,81 @@ def test_gemm_kernel_family_on_ragged_shapes(mode):
                 if mode == 2:
                     cs = A.sum(0)
                     assert float((out[M * N:] - cs).abs().max()) <= 2e-5 * max(1.0, float(cs.abs().max())) * max(1.0, K / 64) ** 0.5
+
+
+def test_two_rank_shards_match_one_full_batch_handle():
+    """The N>1 path through the HIP kernels, without a second GPU: two PpoAlg handles created with world_size = 2, each
+    holding one env shard, against ONE handle holding all envs.  The collectives are done by hand exactly as
+    pointfoot_amd.rsl_rl.dp does them (sum of the 3 advantage scalars; sum of the flat gradient + KL tail), so this
+    exercises gscale = 1 / world_size in ppo_minibatch_apply, the KL tail read by k_prepare_step and the global
+    advantage normalisation.  Ranks must stay in lock-step bit for bit, and equal the full-batch run."""
+    from pointfoot_amd.rsl_rl.modules import ActorCritic
+    from pointfoot_amd.rsl_rl.algorithms import PPO
+    n, T, O, P, A, hidden = 128, 8, 27, 148, 6, [128, 64, 32]
+    dev = "cuda:0"
+
+    def build(N, world, rank):
+        torch.manual_seed(0)
+        alg = PPO(ActorCritic(O, P, A, hidden, hidden, "elu", 1.0), device=dev, **ALG)
+        alg.world_size, alg.rank = world, rank
+        alg.init_storage(N, T, [O], [P], [A])
+        assert alg._cfg.world_size == world
+        return alg
+    full, shards = build(2 * n, 1, 0), [build(n, 2, r) for r in range(2)]
+    for s in shards:
+        assert torch.equal(s.params, full.params)
+    lib = full._lib
+    gen = torch.Generator(device=dev).manual_seed(5)
+    R = lambda *s: torch.randn(*s, device=dev, generator=gen)
+    # a synthetic rollout written straight into the full storage; the shards get their env slices
+    fs = full.storage
+    fs.observations.copy_(R(T, 2 * n, O)); fs.privileged_observations.copy_(R(T, 2 * n, P))
+    fs.actions.copy_(R(T, 2 * n, A)); fs.mu.copy_(fs.actions + 0.1 * R(T, 2 * n, A)); fs.sigma.fill_(1.0)
+    fs.actions_log_prob.copy_((-0.5 * (fs.actions - fs.mu) ** 2 - 0.9189385).sum(-1, keepdim=True))
+    fs.values.copy_(R(T, 2 * n, 1)); fs.rewards.copy_(R(T, 2 * n, 1))
+    fs.dones.copy_((torch.rand(T, 2 * n, 1, device=dev, generator=gen) < 0.1).float())
+    last = R(2 * n, P)
+    names = ("observations", "privileged_observations", "actions", "mu", "sigma", "actions_log_prob", "values", "rewards", "dones")
+    for r, s in enumerate(shards):
+        for k in names:
+            getattr(s.storage, k).copy_(getattr(fs, k)[:, r * n:(r + 1) * n])
+    # returns + GLOBAL advantage normalisation (the 3-scalar all-reduce done by hand)
+    common._abi.check(lib.ppo_compute_returns(full._h, last.data_ptr(), full._stream()))
+    common._abi.check(lib.ppo_normalize_advantages(full._h, full._stream()))
+    for r, s in enumerate(shards):
+        common._abi.check(lib.ppo_compute_returns(s._h, last[r * n:(r + 1) * n].contiguous().data_ptr(), s._stream()))
+    tot = shards[0].scalars[10:13] + shards[1].scalars[10:13]
+    for s in shards:
+        s.scalars[10:13] = tot
+        common._abi.check(lib.ppo_normalize_advantages(s._h, s._stream()))
+    for r, s in enumerate(shards):
+        torch.testing.assert_close(s.storage.advantages, fs.advantages[:, r * n:(r + 1) * n], atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(s.storage.returns, fs.returns[:, r * n:(r + 1) * n], atol=1e-6, rtol=1e-6)
+    # minibatches: the full handle's minibatch k is the union of the two ranks' minibatch k
+    B = n * T // 4
+    local = [torch.randperm(n * T, device=dev, generator=gen) for _ in range(2)]
+    to_full = lambda r, p: (p // n) * (2 * n) + r * n + (p % n)
+    fperm = torch.cat([torch.cat([to_full(r, local[r][k * B:(k + 1) * B]) for r in range(2)]) for k in range(4)])
+    assert torch.equal(torch.sort(fperm).values, torch.arange(2 * n * T, device=dev))
+    full.perm.copy_(fperm.to(torch.int32))
+    for r, s in enumerate(shards):
+        s.perm.copy_(local[r].to(torch.int32))
+    Pn = full.num_params
+    for epoch in range(ALG["num_learning_epochs"]):
+        for mb in range(4):
+            common._abi.check(lib.ppo_minibatch_backward(full._h, mb, full._stream()))
+            common._abi.check(lib.ppo_minibatch_apply(full._h, full._stream()))
+            for s in shards:
+                common._abi.check(lib.ppo_minibatch_backward(s._h, mb, s._stream()))
+            gsum = shards[0].grads + shards[1].grads            # dist.all_reduce(SUM) over the flat gradient and its KL tail
+            for s in shards:
+                s.grads.copy_(gsum)
+                common._abi.check(lib.ppo_minibatch_apply(s._h, s._stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(shards[0].params, shards[1].params), "ranks left lock-step"
+            assert torch.equal(shards[0].scalars[:3], shards[1].scalars[:3])       # lr, mean KL, grad norm
+            assert abs(shards[0].scalars[1].item() - full.scalars[1].item()) <= 1e-6 + 1e-4 * abs(full.scalars[1].item())
+    assert shards[0].scalars[0].item() == full.scalars[0].item(), "adaptive learning-rate decisions differ"
+    assert shards[0].scalars[5].item() == full.scalars[5].item() == 20.0
+    assert (shards[0].params - full.params).abs().max().item() <= 2e-5
+    assert not torch.equal(full.params[:Pn], build(2 * n, 1, 0).params[:Pn])      # the update did move the parameters
