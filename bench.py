@@ -58,11 +58,13 @@ def parse():
 
 
 def make(task, num_envs, device):
+    import contextlib
     from pointfoot_amd.envs import task_registry  # registers tasks
     from pointfoot_amd.utils import get_args
     args = get_args(["--task", task, "--headless", "--num_envs", str(num_envs), "--sim_device", device, "--rl_device", device])
-    env, env_cfg = task_registry.make_env(name=task, args=args)
-    runner, train_cfg = task_registry.make_alg_runner(env=env, name=task, args=args, log_root=None)
+    with contextlib.redirect_stdout(sys.stderr):      # the registry / ActorCritic print like the reference does; stdout carries the JSON line only
+        env, env_cfg = task_registry.make_env(name=task, args=args)
+        runner, train_cfg = task_registry.make_alg_runner(env=env, name=task, args=args, log_root=None)
     return env, runner, train_cfg
 
 
@@ -119,10 +121,33 @@ def cpu_baseline(task, num_envs, threads):
                  old_mu=torch.cat(S["old_mu"]), old_sigma=torch.cat(S["old_sigma"]))
     ppo_ref.update(ac, opt, store, torch.randperm(num_envs * T), cfgd, 1e-3)
     total = time.time() - t0
+    torch.set_num_threads(max(1, min(usable_cpus(), 16)))
     return dict(value=num_envs * T / total, unit="env-steps/s", cores=threads, kind="port",
                 sample=f"1 PPO iteration = {num_envs} envs x {T} steps (oracle C++ env step with OpenMP: {t_collect:.2f}s; "
                        f"torch-CPU PPO 5x4 minibatches: {total - t_collect:.2f}s); restatement CPU baseline, reference binary unavailable",
                 host_cpus=os.cpu_count(), cpu_model=cpu_model())
+
+
+def usable_cpus():
+    """cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (a GPU box hands each job a
+    share of a much larger host; os.cpu_count() reports the whole host)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, q // int(g.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def cpu_model():
@@ -183,6 +208,8 @@ def main():
     for _ in range(a.warmup):
         obs, cobs = iteration(obs, cobs, False)
     torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] warm-up done ({a.warmup} iterations)", file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -201,6 +228,8 @@ def main():
     n_gpus = world
     env_steps = n_gpus * a.num_envs * T * a.steps
     value = env_steps / dt
+    if rank == 0:
+        print(f"[bench] timed region done: {a.steps} iterations in {dt:.3f} s = {value:.0f} env-steps/s", file=sys.stderr, flush=True)
     step_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_pairs]))            # one fused env-step launch
     upd_ms = float(np.mean([s.elapsed_time(e) for s, e in up_pairs]))
     finite = bool(torch.isfinite(runner.alg.params).all().item()) and bool(torch.isfinite(env.rew_buf).all().item())
@@ -258,8 +287,10 @@ def main():
             try:
                 # once at the reference's physx.num_threads (10, pointfoot_rough_config.py:203) and once on
                 # all host cores; one PPO iteration each (a bounded sample: a few seconds of CPU work per run)
-                ncpu = os.cpu_count() or 1
+                ncpu = usable_cpus()
+                print(f"[bench] cpu baseline: 10 threads, then all {ncpu} usable cores (host reports {os.cpu_count()})", file=sys.stderr, flush=True)
                 out["cpu_baseline"] = cpu_baseline(a.task, a.num_envs, min(10, ncpu))
+                print(f"[bench] cpu baseline (10 threads): {out['cpu_baseline']['value']:.0f} env-steps/s", file=sys.stderr, flush=True)
                 if ncpu > 10:
                     out["cpu_baseline"]["all_cores"] = cpu_baseline(a.task, a.num_envs, ncpu)
             except Exception as ex:      # the baseline is informational; never lose the GPU measurement over it

@@ -304,6 +304,9 @@ typedef struct PpoConfig {
   float adam_beta1, adam_beta2, adam_eps;
   int32_t world_size;                     /* data-parallel ranks sharing the gradient */
   uint32_t seed_lo, seed_hi;
+  int32_t gemm_mode;                      /* arithmetic of the dense layers: 0 = default (= 2), 1 = fp32 MFMA (v_mfma_f32_32x32x2_f32),
+                                             2 = fp32 by exact three-way bf16 operand split on the bf16 MFMA ("bf16x6": fp32-grade
+                                             products, fp32 accumulation; csrc/pf_gemm3.h) */
 } PpoConfig;
 
 typedef struct PpoBuffers {

@@ -120,7 +120,7 @@ class PpoConfig(C.Structure):
         ("clip_param", f32), ("value_loss_coef", f32), ("entropy_coef", f32),
         ("gamma", f32), ("lam", f32), ("desired_kl", f32), ("max_grad_norm", f32), ("learning_rate", f32),
         ("adam_beta1", f32), ("adam_beta2", f32), ("adam_eps", f32),
-        ("world_size", i32), ("seed_lo", u32), ("seed_hi", u32),
+        ("world_size", i32), ("seed_lo", u32), ("seed_hi", u32), ("gemm_mode", i32),
     ]
 
 

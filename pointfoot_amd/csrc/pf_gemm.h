@@ -33,6 +33,11 @@ struct GemmArgs {
   int ldh;
   int k_per_split;      // BWD_W: rows of the reduction handled per split (multiple of 32); C slab z at C + z*M*ldc
   int nsplit;           // number of splits (set by pf_gemm_launch)
+  // pf_gemm3.h only: B handed over already split into three bf16 planes, [3][N][ldbp] with k contiguous (weights are split
+  // once per optimiser step, not once per block): plane p at Bp + p * bplane (elements); rows padded with zeros to ldbp % 8 == 0
+  const unsigned short* Bp;
+  int ldbp;
+  long long bplane;
 };
 
 __device__ __forceinline__ float pf_elu(float x) { return x > 0.0f ? x : (__expf(x) - 1.0f); }

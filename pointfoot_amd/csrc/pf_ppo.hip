@@ -18,6 +18,7 @@
 #include "../../include/pointfoot_hip.h"
 #include "../../include/pointfoot_hip_dev.h"
 #include "pf_gemm.h"
+#include "pf_gemm3.h"
 
 void pf_set_error(const std::string& s);
 
@@ -828,11 +829,13 @@ struct PpoAlg {
   // workspace carve (floats)
   size_t w_xa, w_xc, w_act, w_oldlogp, w_oldmu, w_oldsig, w_adv, w_ret, w_oldval;
   size_t w_ha[PPO_MAX_LAYERS], w_hc[PPO_MAX_LAYERS];   // activations per layer output (last = head output)
+  size_t w_wp[2][PPO_MAX_LAYERS], w_wtp[2][PPO_MAX_LAYERS];      // bf16 planes of W (and W^T) per hidden layer, in floats of workspace
   size_t w_dmean, w_dvalue, w_g[2][PPO_MAX_LAYERS], w_slabs[2], w_slabl[2][PPO_MAX_LAYERS + 1], w_partial, w_lastval, w_total;   // [0] actor / [1] critic scratch (run concurrently)
   hipStream_t aux = nullptr;        // second stream: the critic network runs beside the actor network
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool dual = true, fused_heads = true;
   bool paired = true;      // actor + critic layer i in one launch (needs fused_heads and equal depth); else two streams
+  bool split3 = true;      // dense layers on the bf16 matrix pipes by exact three-way operand split (pf_gemm3.h); false: fp32 MFMA
   int max_rows = 0, max_width = 0, splits = 0;
 };
 
@@ -900,12 +903,59 @@ static void ppo_plan(PpoAlg* a) {
       const Layer& L = n.l[i];
       size_t nw = (size_t)L.out * L.in + L.out;
       if (i == n.nl - 1) a->w_slabl[k][i] = take(thin_blocks * nw);
-      else { int tile, S; pf_pick_split(L.out, L.in, (int)R, a->splits, &tile, &S); a->w_slabl[k][i] = take((size_t)(S + 1) * nw); }
+      else {
+        int tile, S, S3;
+        pf_pick_split(L.out, L.in, (int)R, a->splits, &tile, &S);
+        pf_gemm3_pick_split(L.out, L.in, (int)R, a->splits, &tile, &S3);
+        a->w_slabl[k][i] = take((size_t)(std::max(S, S3) + 1) * nw);
+      }
+    }
+  }
+  for (int k = 0; k < 2; ++k) {
+    const Net& n = k == 0 ? a->actor : a->critic;
+    for (int i = 0; i + 1 < n.nl; ++i) {
+      const Layer& L = n.l[i];
+      const size_t inp = (size_t)((L.in + 7) & ~7), outp = (size_t)((L.out + 7) & ~7);
+      a->w_wp[k][i] = take((3 * (size_t)L.out * inp + 1) / 2 + 8);       // bf16 elements -> floats
+      a->w_wtp[k][i] = take((3 * (size_t)L.in * outp + 1) / 2 + 8);
     }
   }
   a->w_partial = take(std::max<size_t>((size_t)RED_BLOCKS * 24, thin_blocks * 20));
   a->w_lastval = take(c.num_envs);
   a->w_total = w;
+}
+
+// bf16 planes of every hidden layer's W and W^T (pf_gemm3.h: the B operand of the forward and data-gradient GEMMs is staged by
+// plain copies instead of being split again by every block).  Re-done at the head of every entry point that runs a dense layer,
+// so the planes can never be stale whoever wrote the parameters (optimiser step, checkpoint load, broadcast): ~4 us per launch.
+static void split_weights(PpoAlg* a, hipStream_t s) {
+  if (!a->split3) return;
+  SplitJobs js; js.n = 0;
+  int blocks = 0;
+  for (int k = 0; k < 2; ++k) {
+    const Net& n = k == 0 ? a->actor : a->critic;
+    for (int i = 0; i + 1 < n.nl; ++i) {
+      const Layer& L = n.l[i];
+      const int inp = (L.in + 7) & ~7, outp = (L.out + 7) & ~7;
+      SplitJob w{a->b.d_params + L.w, reinterpret_cast<unsigned short*>(a->b.d_workspace + a->w_wp[k][i]), L.out, L.in, L.in, inp, 0, (long long)L.out * inp, 0};
+      w.blocks = (int)(((long long)w.rows * w.ldp + 255) / 256);
+      js.j[js.n++] = w; blocks += w.blocks;
+      if (i > 0) {
+        SplitJob t{a->b.d_params + L.w, reinterpret_cast<unsigned short*>(a->b.d_workspace + a->w_wtp[k][i]), L.in, L.out, L.in, outp, 1, (long long)L.in * outp, 0};
+        t.blocks = (int)(((long long)t.rows * t.ldp + 255) / 256);
+        js.j[js.n++] = t; blocks += t.blocks;
+      }
+    }
+  }
+  hipLaunchKernelGGL(k_split_weights, dim3(blocks), dim3(256), 0, s, js);
+}
+// B operand of layer i as planes: the forward GEMM reads W [out][in], the data-gradient GEMM W^T [in][out]
+static void use_planes(PpoAlg* a, GemmArgs& g, int net, int layer, bool transposed) {
+  if (!a->split3) return;
+  const Layer& L = (net == 0 ? a->actor : a->critic).l[layer];
+  const int inp = (L.in + 7) & ~7, outp = (L.out + 7) & ~7;
+  if (!transposed) { g.Bp = reinterpret_cast<const unsigned short*>(a->b.d_workspace + a->w_wp[net][layer]); g.ldbp = inp; g.bplane = (long long)L.out * inp; }
+  else { g.Bp = reinterpret_cast<const unsigned short*>(a->b.d_workspace + a->w_wtp[net][layer]); g.ldbp = outp; g.bplane = (long long)L.in * outp; }
 }
 
 // forward through one MLP: X[M, in0] -> activations; hidden layers on the MFMA GEMM (bias + ELU fused), head on the thin kernel
@@ -923,7 +973,9 @@ static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const si
     } else {
       GemmArgs g{};
       g.A = in; g.B = P + L.w; g.C = out; g.M = M; g.N = L.out; g.K = L.in; g.lda = L.in; g.ldb = L.in; g.ldc = L.out; g.bias = P + L.b;
-      pf_gemm_auto<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
+      use_planes(a, g, &n == &a->actor ? 0 : 1, i, false);
+      if (a->split3) pf_gemm3_launch<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
+      else pf_gemm_auto<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
     }
     in = out;
   }
@@ -959,7 +1011,11 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
       GemmArgs g{};
       g.A = gcur; g.B = P + L.w; g.C = g_of(i - 1); g.M = M; g.N = L.in; g.K = L.out; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
       g.H = ws + w_h[i - 1]; g.ldh = L.in;
-      pf_gemm_auto<true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
+      if (a->split3) {      // B = W^T planes, k (= out) contiguous
+        use_planes(a, g, &n == &a->actor ? 0 : 1, i, true);
+        pf_gemm3_launch<true, true, GEMM_EPI_MUL_DELU>(g, 0, s);
+      }
+      else pf_gemm_auto<true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
     }
     // dW_i = gcur[M, out]^T * in[M, in] and db_i = column sums of gcur, both as split-K slabs [S][out*in + out]
     // (deterministic slab reduce straight into the flat gradient: W then b)
@@ -967,11 +1023,13 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
       GemmArgs g{};
       g.A = gcur; g.B = in; g.C = slabs; g.M = L.out; g.N = L.in; g.K = M; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
       int tile, want;
-      pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
+      if (a->split3) pf_gemm3_pick_split(L.out, L.in, M, a->splits, &tile, &want);
+      else pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
       int per = ((M + want - 1) / want + 31) / 32 * 32;
       int S = (M + per - 1) / per;
       g.k_per_split = per;
-      if (tile == 0) pf_gemm_launch<128, 128, false, false, GEMM_EPI_NONE, true>(g, S, s);
+      if (a->split3) pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g, S, s, tile);
+      else if (tile == 0) pf_gemm_launch<128, 128, false, false, GEMM_EPI_NONE, true>(g, S, s);
       else if (tile == 1) pf_gemm_launch<128, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
       else pf_gemm_launch<64, 64, false, false, GEMM_EPI_NONE, true>(g, S, s);
       int nw = L.out * L.in + L.out;
@@ -1003,7 +1061,9 @@ static void mlp_forward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M,
   const float *ina = Xa, *inc = Xc;
   for (int i = 0; i + 1 < a->actor.nl; ++i) {       // hidden layers; the heads run in k_heads / k_act_heads
     GemmArgs ga = fwd_args(a, a->actor, i, ina, a->w_ha, M), gc = fwd_args(a, a->critic, i, inc, a->w_hc, M);
-    pf_gemm_auto2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);     // the larger problem (critic) first
+    use_planes(a, ga, 0, i, false); use_planes(a, gc, 1, i, false);
+    if (a->split3) pf_gemm3_launch2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);
+    else pf_gemm_auto2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);     // the larger problem (critic) first
     ina = ws + a->w_ha[i]; inc = ws + a->w_hc[i];
   }
 }
@@ -1028,23 +1088,33 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
         g[k].A = g_of(k, i); g[k].B = P + L.w; g[k].C = g_of(k, i - 1); g[k].M = M; g[k].N = L.in; g[k].K = L.out;
         g[k].lda = L.out; g[k].ldb = L.in; g[k].ldc = L.in; g[k].H = ws + w_h[k][i - 1]; g[k].ldh = L.in;
       }
-      pf_gemm_auto2<true, false, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
+      if (a->split3) {      // B = W^T planes, k (= out) contiguous
+        use_planes(a, g[0], 0, i, true); use_planes(a, g[1], 1, i, true);
+        pf_gemm3_launch2<true, true, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
+      }
+      else pf_gemm_auto2<true, false, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
     }
     // dW_i, db_i as split-K slabs, then the deterministic slab reduce straight into the flat gradient
-    GemmArgs g[2]; int S[2]; ReduceJob j[2];
+    GemmArgs g[2]; int S[2], tiles3[2] = {0, 0}; ReduceJob j[2];
     for (int k = 0; k < 2; ++k) {
       const Layer& L = net[k]->l[i];
       g[k] = GemmArgs{};
       g[k].A = g_of(k, i); g[k].B = i == 0 ? X[k] : ws + w_h[k][i - 1]; g[k].C = ws + a->w_slabl[k][i];
       g[k].M = L.out; g[k].N = L.in; g[k].K = M; g[k].lda = L.out; g[k].ldb = L.in; g[k].ldc = L.in;
       int tile, want;
-      pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
+      if (a->split3) pf_gemm3_pick_split(L.out, L.in, M, a->splits, &tile, &want);
+      else pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
       int per = ((M + want - 1) / want + 31) / 32 * 32;
       S[k] = (M + per - 1) / per;
       g[k].k_per_split = per;
+      tiles3[k] = tile;
       j[k] = reduce_plan(L.out * L.in + L.out, S[k], ws + a->w_slabl[k][i], G + L.w);
     }
-    pf_gemm_launch2<false, false, GEMM_EPI_NONE, true>(g[1], S[1], g[0], S[0], s);
+    if (a->split3) {
+      // the actor's and the critic's weight gradients differ in shape (27 vs 148 inputs): one launch each, back to back
+      pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g[1], S[1], s, tiles3[1]);
+      pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g[0], S[0], s, tiles3[0]);
+    } else pf_gemm_launch2<false, false, GEMM_EPI_NONE, true>(g[1], S[1], g[0], S[0], s);
     js.j[js.n++] = j[1]; js.j[js.n++] = j[0];
   }
   reduce_slabs_n(js, s);      // every layer has its own slabs: one reduction launch for the whole pass
@@ -1083,6 +1153,34 @@ int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, 
     else pf_gemm_launch<64, 64, AK, BK_, E, CS>(g, S, s);
   };
   using T = std::true_type; using F = std::false_type;
+  if (mode >= 20) {      // bf16x6 with B (the weights) pre-split into bf16 planes in `ws`, as the PPO path runs the dense layers
+    const int Kp = (K + 7) & ~7;
+    SplitJobs js; js.n = 1;
+    // mode 20: B = W [N][K];  mode 21: B = W [K][N], planes of W^T [N][K]
+    js.j[0] = SplitJob{B, reinterpret_cast<unsigned short*>(ws), N, K, mode == 20 ? K : N, Kp, mode == 20 ? 0 : 1, (long long)N * Kp, 0};
+    js.j[0].blocks = (int)(((long long)N * Kp + 255) / 256);
+    hipLaunchKernelGGL(k_split_weights, dim3(js.j[0].blocks), dim3(256), 0, s, js);
+    g.lda = K; g.ldb = K; g.Bp = reinterpret_cast<const unsigned short*>(ws); g.ldbp = Kp; g.bplane = (long long)N * Kp;
+    if (mode == 20) pf_gemm3_launch<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s, tile);
+    else pf_gemm3_launch<true, true, GEMM_EPI_MUL_DELU>(g, 0, s, tile);
+    PPO_HIP_OK(hipGetLastError());
+    return 0;
+  }
+  if (mode >= 10) {      // the same three arrangements on the bf16x6 path (tile: -1 auto, 0 128x128, 1 128x64, 2 64x128, 3 64x64)
+    if (mode == 10) { g.lda = K; g.ldb = K; pf_gemm3_launch<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s, tile); }
+    else if (mode == 11) { g.lda = K; g.ldb = N; pf_gemm3_launch<true, false, GEMM_EPI_MUL_DELU>(g, 0, s, tile); }
+    else {
+      g.lda = M; g.ldb = N; g.C = ws;
+      int want = splits, t3 = tile;
+      if (tile < 0) pf_gemm3_pick_split(M, N, K, splits, &t3, &want);
+      int per = ((K + want - 1) / want + 31) / 32 * 32, S = (K + per - 1) / per;
+      g.k_per_split = per;
+      pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g, S, s, t3);
+      reduce_slabs(M * N + M, S, ws, Cm, s);
+    }
+    PPO_HIP_OK(hipGetLastError());
+    return 0;
+  }
   if (mode == 0) { g.lda = K; g.ldb = K; run(T{}, T{}, std::integral_constant<int, GEMM_EPI_BIAS_ELU>{}, F{}, 0); }
   else if (mode == 1) { g.lda = K; g.ldb = N; run(T{}, F{}, std::integral_constant<int, GEMM_EPI_MUL_DELU>{}, F{}, 0); }
   else {
@@ -1125,6 +1223,8 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
   PpoAlg* a = new PpoAlg();
   a->cfg = *cfg; a->device = device;
   ppo_plan(a);
+  a->split3 = cfg->gemm_mode != 1;
+  if (const char* gm = getenv("PF_PPO_GEMM")) a->split3 = atoi(gm) != 1;       // diagnostics: 1 = fp32 MFMA, 2 = bf16x6
   if (const char* fh = getenv("PF_PPO_FUSED_HEADS")) a->fused_heads = atoi(fh) != 0;
   if (const char* pr = getenv("PF_PPO_PAIRED")) a->paired = atoi(pr) != 0;
   a->paired = a->paired && a->fused_heads && a->actor.nl == a->critic.nl;
@@ -1167,6 +1267,7 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   hipStream_t s = (hipStream_t)stream;
   const int N = c.num_envs, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   float* ws = a->b.d_workspace;
+  split_weights(a, s);
   hipStream_t s2 = a->paired ? s : ppo_fork(a, s);
   size_t tn = (size_t)t * N;
   if (a->fused_heads) {
@@ -1202,6 +1303,7 @@ int ppo_act_inference(PpoAlg* a, const float* d_obs, int32_t n, float* d_actions
   if (ppo_wrong_device(a)) return 1;
   if (n < 1 || n > a->max_rows) { pf_set_error("ppo_act_inference: batch larger than the workspace"); return 1; }
   hipStream_t s = (hipStream_t)stream;
+  split_weights(a, s);
   mlp_forward(a, a->actor, d_obs, n, a->w_ha, s);
   PPO_HIP_OK(hipMemcpyAsync(d_actions_out, a->b.d_workspace + a->w_ha[a->actor.nl - 1], sizeof(float) * n * a->cfg.num_actions,
                             hipMemcpyDeviceToDevice, s));
@@ -1228,6 +1330,7 @@ int ppo_compute_returns(PpoAlg* a, const float* d_last_critic_obs, void* stream)
   hipStream_t s = (hipStream_t)stream;
   float* ws = a->b.d_workspace;
   const int N = c.num_envs, T = c.num_steps;
+  split_weights(a, s);
   mlp_forward(a, a->critic, d_last_critic_obs, N, a->w_hc, s);
   PPO_HIP_OK(hipMemcpyAsync(ws + a->w_lastval, ws + a->w_hc[a->critic.nl - 1], sizeof(float) * N, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(k_gae, dim3((N + 255) / 256), dim3(256), 0, s, N, T, c.gamma, c.lam, ws + a->w_lastval, a->b.d_values, a->b.d_rewards,
@@ -1257,6 +1360,7 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
   float* ws = a->b.d_workspace;
   const int B = a->batch, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   const int* perm = a->b.d_perm + (size_t)mb * B;
+  split_weights(a, s);
   {
     GatherArgs ga;
     const float* srcs[9] = {a->b.d_obs, a->b.d_critic_obs, a->b.d_actions, a->b.d_log_prob, a->b.d_mu, a->b.d_sigma, a->b.d_advantages,

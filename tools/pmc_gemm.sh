@@ -1,0 +1,12 @@
+#!/bin/bash
+# PMC passes on one GEMM shape: bash tools/pmc_gemm.sh <tag> MODE M N K TILE FAM
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC SQ_WAVES"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d $O/${TAG}_pmc$i -- python3 $R/tools/gemm_one.py "$@" > $O/${TAG}_pmc$i.log 2>&1
+  f=$(find $O/${TAG}_pmc$i -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 $R/tools/pmc_summary.py $f gemm | tail -8
+done
