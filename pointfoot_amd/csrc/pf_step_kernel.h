@@ -284,8 +284,11 @@ struct PfKernel {
     const float H00 = vs * (float)hs[ix * c.hf_cols + iy], H10 = vs * (float)hs[(ix + 1) * c.hf_cols + iy],
                 H01 = vs * (float)hs[ix * c.hf_cols + iy + 1], H11 = vs * (float)hs[(ix + 1) * c.hf_cols + iy + 1];
     float E00 = H00, E10 = H10, E01 = H01, E11 = H11;
-    if (thr > 0.0f) {
-      const float lo = fminf(fminf(H00, H10), fminf(H01, H11));
+    const float lo = fminf(fminf(H00, H10), fminf(H01, H11)), hi = fmaxf(fmaxf(H00, H10), fmaxf(H01, H11));
+    // a cell whose corners lie within wall_threshold of each other has no face and no lowered corner: the common case,
+    // skipped as a whole when no lane of the wavefront stands on a step
+    const bool steep = thr > 0.0f && hi - lo > thr;
+    if (steep) {
       E00 = (H00 - lo > thr) ? lo : H00; E10 = (H10 - lo > thr) ? lo : H10;
       E01 = (H01 - lo > thr) ? lo : H01; E11 = (H11 - lo > thr) ? lo : H11;
     }
@@ -294,7 +297,7 @@ struct PfKernel {
     float dhdy = ((1.0f - tx) * (E01 - E00) + tx * (E11 - E10)) / hsc;
     float inv = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
     n[0] = -dhdx * inv; n[1] = -dhdy * inv; n[2] = inv;
-    if (thr > 0.0f) {
+    if (steep) {
       // 0: x-far (normal -x), 1: x-near (+x), 2: y-far (-y), 3: y-near (+y)
       const float top[4] = {(1.0f - ty) * H10 + ty * H11, (1.0f - ty) * H00 + ty * H01, (1.0f - tx) * H01 + tx * H11, (1.0f - tx) * H00 + tx * H10};
       const float bot[4] = {(1.0f - ty) * E10 + ty * E11, (1.0f - ty) * E00 + ty * E01, (1.0f - tx) * E01 + tx * E11, (1.0f - tx) * E00 + tx * E10};
@@ -439,7 +442,10 @@ struct PfKernel {
         for (int t = 0; t < 6; ++t) { sh.V[0][t] = V0[t]; sh.A[0][t] = A0[t]; sh.Sj[0][t] = 0.0f; }
       }
     }
-    // one lane per root-to-leaf chain: the parent's frame stays in registers, no barrier between tree levels
+    // one lane per root-to-leaf chain: the parent's frame stays in registers, no barrier between tree levels.  (A level-
+    // synchronous form with 16 lanes per chain -- one matrix element / vector component per lane, 3-term dot products through
+    // LDS -- was built and measured: 133.6 vs 126.3 us per launch.  With two wavefronts per SIMD the kernel is bound by
+    // LDS-round-trip latency, not by instruction count: the serial register walk keeps the VALU fed.)
     PF_LANES(ch, m.nchain) {
       float Rp[9], rp[3] = {0.0f, 0.0f, 0.0f}, Vp[6], Ap[6];
 #pragma unroll
@@ -882,7 +888,11 @@ struct PfKernel {
       const bool tv = tl < NV;
       auto rsum = [](float x) { if constexpr (NV <= 16) return pf_row16_sum(x); else return pf_group32_sum(x); };
       float v = tv ? sh.vel[tl] : 0.0f;
-      float jc[MAXC][3], wc[MAXC][3], lc[MAXC][3], jl[ND], wl[ND], ll[ND];
+      // joint-limit rows: the first LREG live in registers like the contact rows; the 12-DOF instance keeps the rest in LDS
+      // (J = +-e_k is rebuilt from lim_dof / lim_side, W and the impulse are read where they lie) -- 24 VGPRs the
+      // quadruped kernel does not have (ANYmal's joints are continuous: no limit row is ever active there)
+      constexpr int LREG = ND <= 6 ? ND : 4;
+      float jc[MAXC][3], wc[MAXC][3], lc[MAXC][3], jl[LREG], wl[LREG], ll[LREG];
 #pragma unroll
       for (int ci = 0; ci < MAXC; ++ci)
 #pragma unroll
@@ -893,7 +903,7 @@ struct PfKernel {
           lc[ci][d] = on ? sh.lam[3 * ci + d] : 0.0f;
         }
 #pragma unroll
-      for (int li = 0; li < ND; ++li) {
+      for (int li = 0; li < LREG; ++li) {
         const bool on = li < nlim;
         jl[li] = (on && tv) ? sh.J[CROWS + li][tl] : 0.0f;
         wl[li] = (on && tv) ? sh.W[CROWS + li][tl] : 0.0f;
@@ -921,7 +931,7 @@ struct PfKernel {
           }
         }
 #pragma unroll
-        for (int li = 0; li < ND; ++li) {
+        for (int li = 0; li < LREG; ++li) {
           if (li < nlim) {
             const int rr = CROWS + li;
             const float u = rsum(jl[li] * v);
@@ -931,6 +941,17 @@ struct PfKernel {
             ll[li] = ln;
           }
         }
+        if constexpr (LREG < ND) {
+          for (int li = LREG; li < nlim; ++li) {      // rows kept in LDS (every lane stores the same impulse: no barrier needed)
+            const int rr = CROWS + li;
+            const float jv = (tv && tl == 6 + sh.lim_dof[li]) ? (float)sh.lim_side[sh.lim_dof[li]] : 0.0f;
+            const float u = rsum(jv * v);
+            const float lo = sh.lam[rr];
+            const float ln = fmaxf(0.0f, lo + (sh.rb[rr] - u) * sh.rAinv[rr]);
+            v += (tv ? sh.W[rr][tl] : 0.0f) * (ln - lo);
+            sh.lam[rr] = ln;
+          }
+        }
       }
       PF_SYNC();
       if (PF_LANE_ID < NV) sh.vel[PF_LANE_ID] = v;
@@ -938,7 +959,7 @@ struct PfKernel {
 #pragma unroll
         for (int ci = 0; ci < MAXC; ++ci) if (ci < ncon) { sh.lam[3 * ci] = lc[ci][0]; sh.lam[3 * ci + 1] = lc[ci][1]; sh.lam[3 * ci + 2] = lc[ci][2]; }
 #pragma unroll
-        for (int li = 0; li < ND; ++li) if (li < nlim) sh.lam[CROWS + li] = ll[li];
+        for (int li = 0; li < LREG; ++li) if (li < nlim) sh.lam[CROWS + li] = ll[li];
       }
       PF_SYNC();
     } else
@@ -1244,9 +1265,8 @@ struct PfKernel {
       PF_LANES(i, L.rec_floats) grow[i] = S[i];
       return;
     }
-    if (g.mode == 2) {
-      float* hts = heights_of(sh);
-      PF_LANES(j, c.num_height_points) hts[j] = B.d_measured_heights ? B.d_measured_heights[(size_t)env * c.num_height_points + j] : 0.0f;
+    if (g.mode == 2) {      // compute_observations() (:123-129, :320-326): measured_heights are taken afresh (:213 / :324)
+      if (c.measure_heights) (void)height_scan(sh, c, B, env);
       PF_SYNC();
       observations(sh, c, L, B, inj, env, g.step_counter);
       return;
@@ -1312,6 +1332,35 @@ struct PfKernel {
 #endif
   }
 
+  // ------------------------------------------------------------------ _get_heights (:1048-1075): one scan point per lane
+  // fills heights_of(sh); returns the sum over the points of (root z - height) (every lane: the base-height reward's mean)
+  PF_DEV float height_scan(Shared& sh, const PfConfig& c, const PfBuffers& B, int env) {
+#if !defined(PF_HOST_EMU)
+#pragma clang fp contract(off)
+#endif
+    const float* S = sh.rec;
+    float* hts = heights_of(sh);
+    const int H = c.num_height_points;
+    const float root_z = S[LC::root + 2];
+    float qy[4] = {0.0f, 0.0f, S[LC::root + 5], S[LC::root + 6]};
+    float nrm = sqrtf(qy[2] * qy[2] + qy[3] * qy[3]);
+    nrm = nrm < 1e-9f ? 1e-9f : nrm;
+    qy[2] /= nrm; qy[3] /= nrm;
+    float hsum = 0.0f;
+    PF_LANES(j, H) {
+      float hv = 0.0f;
+      if (c.terrain_type != PF_TERRAIN_PLANE) {
+        float pl[3] = {c.height_px[j], c.height_py[j], 0.0f}, pw[3];
+        pf_quat_apply(qy, pl, pw);
+        hv = height_raw(c, B.d_height_samples, pw[0] + S[LC::root], pw[1] + S[LC::root + 1]) * c.vscale;
+      }
+      hts[j] = hv;
+      if (B.d_measured_heights) B.d_measured_heights[(size_t)env * H + j] = hv;      // only when a caller asked for the tensor
+      hsum += root_z - hv;
+    }
+    return PF_WAVE_SUM(hsum);
+  }
+
   // ------------------------------------------------------------------ post_physics_step (:195-230)
   PF_DEV void post_physics(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
 #if !defined(PF_HOST_EMU)
@@ -1331,27 +1380,10 @@ struct PfKernel {
       float lv[3] = {S[LC::root + 7], S[LC::root + 8], S[LC::root + 9]}, av[3] = {S[LC::root + 10], S[LC::root + 11], S[LC::root + 12]}, gv[3] = {0.0f, 0.0f, -1.0f};
       pf_quat_rotate_dir(q, lv, -1.0f, blv); pf_quat_rotate_dir(q, av, -1.0f, bav); pf_quat_rotate_dir(q, gv, -1.0f, pg);
     }
-    // :212-213, :1048-1075 height scan — one point per lane
+    // :212-213, :1048-1075 height scan -- one point per lane
     float root_z = S[LC::root + 2];
     float hsum = 0.0f;
-    if (c.measure_heights) {
-      float qy[4] = {0.0f, 0.0f, q[2], q[3]};
-      float nrm = sqrtf(qy[2] * qy[2] + qy[3] * qy[3]);
-      nrm = nrm < 1e-9f ? 1e-9f : nrm;
-      qy[2] /= nrm; qy[3] /= nrm;
-      PF_LANES(j, H) {
-        float hv = 0.0f;
-        if (c.terrain_type != PF_TERRAIN_PLANE) {
-          float pl[3] = {c.height_px[j], c.height_py[j], 0.0f}, pw[3];
-          pf_quat_apply(qy, pl, pw);
-          hv = height_raw(c, B.d_height_samples, pw[0] + S[LC::root], pw[1] + S[LC::root + 1]) * c.vscale;
-        }
-        hts[j] = hv;
-        if (B.d_measured_heights) B.d_measured_heights[(size_t)env * H + j] = hv;
-        hsum += root_z - hv;
-      }
-      hsum = PF_WAVE_SUM(hsum);
-    }
+    if (c.measure_heights) hsum = height_scan(sh, c, B, env);
     // :1114-1129 feet state machine (PointFoot only; LeggedRobot keeps it inside _reward_feet_air_time)
     if constexpr (!LR) PF_LANES(f, NF) {
       bool first = S[LC::first_contact + f] != 0.0f, filt = S[LC::contact_filt + f] != 0.0f;

@@ -146,6 +146,21 @@ class HipEnv:
         pass
 
     @property
+    def measured_heights(self):
+        """reference :213 / :1048-1075: (N, H) heights under the scan points, 0 when heights are not measured.  The step
+        kernel consumes the scan in LDS; the tensor exists (and is written by every following step, 2 MB per launch at
+        4096 envs) only once somebody has asked for it."""
+        H = self._cfg_c.num_height_points
+        if not H:
+            return 0
+        if self._measured_heights is None:
+            self._measured_heights = torch.zeros(self.num_envs, H, device=self.device, dtype=torch.float)
+            self._bufs.d_measured_heights = _native.ptr(self._measured_heights)
+            _abi.check(self._lib.pf_bind_buffers(self._h, C.byref(self._bufs)), self._lib)
+            self.compute_observations()       # fills it for the current state
+        return self._measured_heights
+
+    @property
     def episode_length_buf(self):
         return self._episode_length_buf
 
@@ -433,7 +448,7 @@ class HipEnv:
         self.terminate = torch.zeros(N, device=dev, dtype=torch.bool)
         self._episode_length_buf = torch.zeros(N, device=dev, dtype=torch.long)
         H = self._cfg_c.num_height_points
-        self.measured_heights = torch.zeros(N, H, device=dev, dtype=torch.float) if H else 0
+        self._measured_heights = None      # (N, H) tensor once somebody reads `measured_heights` (see the property)
         self._stats_ring = torch.zeros(64, _abi.PF_STATS_FLOATS, device=dev, dtype=torch.float)      # see ensure_stats_ring
         self.joint_friction = None       # (N, num_dof) after the first update_frictions call
         self._stats_slot = 0
@@ -467,7 +482,7 @@ class HipEnv:
         b.d_reset, b.d_time_out, b.d_terminate = p(self.reset_buf), p(self.time_out_buf), p(self.terminate)
         b.d_obs, b.d_priv, b.d_rew = p(self.obs_buf), p(self.privileged_obs_buf), p(self.rew_buf)
         b.d_actuator_params = p(getattr(self, "_actuator_params", None))
-        b.d_measured_heights = p(self.measured_heights if H else None)
+        b.d_measured_heights = p(None)      # the kernel keeps the scan in LDS; the tensor is written only on request
         b.d_height_samples = p(self.height_samples)
         b.d_terrain_origins = p(self.terrain_origins)
         b.d_reset_stats = p(self._reset_stats)

@@ -57,6 +57,17 @@ def test_env_class_matches_oracle_and_protocol(task):
             assert bool(extras["time_outs"][:3].all())     # episode length 1001 > 1000
         ep = extras["episode"]
         assert set(k for k in ep if k.startswith("rew_")) == {"rew_" + k for k in env.reward_names}
+        if rough and t == 2:
+            # `measured_heights` is materialised on first access (the kernel keeps the scan in LDS otherwise) ...
+            assert env._measured_heights is None
+            mh = env.measured_heights
+            torch.cuda.synchronize()
+            keep = ~sim.reset.astype(bool) & same
+            np.testing.assert_allclose(mh.cpu().numpy()[keep], sim.heights[keep], atol=1e-6)
+        if rough and t == 3:      # ... and is then written by every step
+            keep = ~sim.reset.astype(bool) & same
+            assert int(keep.sum()) > 32
+            np.testing.assert_allclose(env.measured_heights.cpu().numpy()[keep], sim.heights[keep], atol=1e-6)
         assert ("terrain_level" in ep) == rough
     # live views: scripts write commands / read dof state like on the reference's wrapped tensors
     env.commands[0, 0] = 0.7
