@@ -37,7 +37,7 @@ def step_traffic(kernel_prefix, task, num_envs):
     try:
         with open(TRAFFIC_PROFILE) as f:
             p = json.load(f)
-        if p["kernel"].startswith(kernel_prefix) and p["task"] == task and int(p["num_envs"]) == num_envs:
+        if kernel_prefix in p["kernel"].replace(" ", "") and p["task"] == task and int(p["num_envs"]) == num_envs:
             return float(p["traffic_bytes_per_launch"]), os.path.relpath(TRAFFIC_PROFILE, ROOT)
     except (OSError, KeyError, ValueError):
         pass

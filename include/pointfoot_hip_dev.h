@@ -25,6 +25,10 @@ int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, 
 /* Diagnostic build (-DPF_STAMPS, tools/step_stamps.py) only: per-env phase cycle counters, 16 unsigned per env. */
 int pf_debug_set_stamps(PfEnv* env, unsigned* d_stamps);
 
+/* Calibration of the rocprofv3 FETCH_SIZE counter on the step kernel's own read pattern (dword per lane, 32 lanes per
+ * record row): reads rows x row_floats floats once; tools/calib_fetch.py compares the counter with the known byte count. */
+int pf_debug_calib_read(const float* d_src, int rows, int row_floats, float* d_sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

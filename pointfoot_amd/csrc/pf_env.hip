@@ -66,7 +66,23 @@ struct PfEnv {
   float* stats_cleared = nullptr; // slot already cleared on the device by the previous launch
 };
 
+// development hook: a read stream with the step kernel's record access pattern (each 32-lane group walks a 640-byte row, one
+// dword per lane) over a buffer of known size -- the byte count FETCH_SIZE is calibrated against (tools/calib_fetch.py)
+__global__ void pf_calib_read_kernel(const float* __restrict__ src, int rows, int row_floats, float* __restrict__ sink) {
+  const int row = (int)blockIdx.x * 2 + ((int)threadIdx.x >> 5), lane = (int)threadIdx.x & 31;
+  if (row >= rows) return;
+  float acc = 0.0f;
+  for (int i = lane; i < row_floats; i += 32) acc += src[(size_t)row * row_floats + i];
+  if (acc == 1234.5678f) sink[0] = acc;      // keeps the loads alive without a store stream
+}
+
 extern "C" {
+
+int pf_debug_calib_read(const float* d_src, int rows, int row_floats, float* d_sink, void* stream) {
+  hipLaunchKernelGGL(pf_calib_read_kernel, dim3((rows + 1) / 2), dim3(64), 0, (hipStream_t)stream, d_src, rows, row_floats, d_sink);
+  PF_HIP_OK(hipGetLastError());
+  return 0;
+}
 
 const char* pf_last_error(void) { return g_pf_error.c_str(); }
 
