@@ -304,9 +304,9 @@ typedef struct PpoConfig {
   float adam_beta1, adam_beta2, adam_eps;
   int32_t world_size;                     /* data-parallel ranks sharing the gradient */
   uint32_t seed_lo, seed_hi;
-  int32_t gemm_mode;                      /* arithmetic of the dense layers: 0 = default (= 2), 1 = fp32 MFMA (v_mfma_f32_32x32x2_f32),
-                                             2 = fp32 by exact three-way bf16 operand split on the bf16 MFMA ("bf16x6": fp32-grade
-                                             products, fp32 accumulation; csrc/pf_gemm3.h) */
+  int32_t gemm_mode;                      /* arithmetic of the dense layers: 1 = fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 = fp32 by exact
+                                             three-way bf16 operand split on the bf16 MFMA ("bf16x6": fp32-grade products, fp32
+                                             accumulation; csrc/pf_gemm3.h); 0 = by size (2 when a hidden layer is >= 256 wide) */
 } PpoConfig;
 
 typedef struct PpoBuffers {
@@ -349,7 +349,9 @@ int32_t ppo_param_offsets(const PpoConfig* cfg, int64_t* offsets, int32_t max_en
 int64_t ppo_workspace_floats(const PpoConfig* cfg);
 
 /* PPO.act: actor+critic forward on (obs, critic_obs), Normal(mu, std).sample(), log-prob, store
- * transition `t` (rsl_rl PPO.act + RolloutStorage.add_transitions).  d_actions_out (N,A). */
+ * transition `t` (rsl_rl PPO.act + RolloutStorage.add_transitions).  d_actions_out (N,A).
+ * The caller may rewrite d_params between rollouts (checkpoint load, broadcast); derived copies of the weights are refreshed
+ * at t == 0 and by every other entry point that runs a dense layer, not between the transitions of one rollout. */
 int ppo_act(PpoAlg* alg, int32_t t, const float* d_obs, const float* d_critic_obs, float* d_actions_out,
             int64_t sample_counter, const float* d_inject_normal, void* stream);
 /* actor forward only (act_inference / get_inference_policy) */

@@ -4,6 +4,7 @@
  * needs none of it.  Users: tests/test_gpu_ppo.py (GEMM family test), tools/gemm_bench.py, tools/step_stamps.py.
  *
  * Environment switches read by the library (diagnostics only; the defaults are the product path):
+ *   PF_PPO_GEMM=1|2        dense layers on the fp32 MFMA kernels (1) or on the bf16-split kernels (2), overriding PpoConfig.gemm_mode
  *   PF_PPO_PAIRED=0        actor / critic layers as separate launches on two streams instead of one paired launch
  *   PF_PPO_FUSED_HEADS=0   unfused head / loss / head-backward kernels
  *   PF_PPO_DUAL_STREAM=0   (with PAIRED=0) single stream
@@ -16,7 +17,8 @@
 extern "C" {
 #endif
 
-/* Run one GEMM of the PPO kernel family.  mode 0: C[M,N] = A[M,K] B[N,K]^T + bias, ELU;  1: C[M,N] = A[M,K] B[K,N] * ELU'(H);
+/* Run one GEMM of the PPO kernel family (modes 0-2: fp32 MFMA, pf_gemm.h; 10-12: the same arrangements on the bf16-split
+ * kernels, pf_gemm3.h; 20 / 21: forward / data gradient with B pre-split into bf16 planes in `ws`).  mode 0: C[M,N] = A[M,K] B[N,K]^T + bias, ELU;  1: C[M,N] = A[M,K] B[K,N] * ELU'(H);
  * 2: C[M,N] = A[K,M]^T B[K,N] as split-K slabs into `ws`, reduced into C, column sums of A in C[M*N .. M*N+M).
  * tile: -1 auto, 0: 128x128, 1: 128x64, 2: 64x64. */
 int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, float* C, const float* bias, const float* H,

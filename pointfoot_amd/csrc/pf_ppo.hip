@@ -1223,8 +1223,16 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
   PpoAlg* a = new PpoAlg();
   a->cfg = *cfg; a->device = device;
   ppo_plan(a);
-  a->split3 = cfg->gemm_mode != 1;
-  if (const char* gm = getenv("PF_PPO_GEMM")) a->split3 = atoi(gm) != 1;       // diagnostics: 1 = fp32 MFMA, 2 = bf16x6
+  {
+    // gemm_mode 0: pick by size.  The bf16-split kernels win on the 512/256/128-wide networks (pointfoot_rough, the
+    // quadrupeds: 11.8 vs 13.2 ms per update); on pointfoot_flat's 128/64/32 layers the plain fp32 MFMA kernels do
+    // (2.9 vs 3.5 ms): there is too little arithmetic per tile to pay for splitting the operands.
+    int widest = 0;
+    for (int i = 1; i < cfg->n_actor_layers; ++i) widest = std::max(widest, cfg->actor_dims[i]);
+    for (int i = 1; i < cfg->n_critic_layers; ++i) widest = std::max(widest, cfg->critic_dims[i]);
+    a->split3 = cfg->gemm_mode == 2 || (cfg->gemm_mode == 0 && widest >= 256);
+  }
+  if (const char* gm = getenv("PF_PPO_GEMM")) a->split3 = atoi(gm) == 2;       // diagnostics: 1 = fp32 MFMA, 2 = bf16x6
   if (const char* fh = getenv("PF_PPO_FUSED_HEADS")) a->fused_heads = atoi(fh) != 0;
   if (const char* pr = getenv("PF_PPO_PAIRED")) a->paired = atoi(pr) != 0;
   a->paired = a->paired && a->fused_heads && a->actor.nl == a->critic.nl;
@@ -1267,7 +1275,7 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   hipStream_t s = (hipStream_t)stream;
   const int N = c.num_envs, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   float* ws = a->b.d_workspace;
-  split_weights(a, s);
+  if (t == 0) split_weights(a, s);      // parameters only change between rollouts (optimiser step, checkpoint load, broadcast)
   hipStream_t s2 = a->paired ? s : ppo_fork(a, s);
   size_t tn = (size_t)t * N;
   if (a->fused_heads) {

@@ -76,8 +76,8 @@ def ref_store(alg):
 # execution variants of the same arithmetic (read by ppo_create): default = dense layers by exact bf16 split on the bf16 matrix
 # pipes (pf_gemm3.h), actor and critic layers paired in one launch, fused head kernels; PF_PPO_GEMM=1 selects the plain fp32
 # MFMA GEMMs; the other fallbacks run the critic on a second stream / the separate head, loss and sampling kernels
-VARIANTS = [{}, {"PF_PPO_GEMM": "1"}, {"PF_PPO_PAIRED": "0"}, {"PF_PPO_PAIRED": "0", "PF_PPO_GEMM": "1"}, {"PF_PPO_FUSED_HEADS": "0"},
-            {"PF_PPO_FUSED_HEADS": "0", "PF_PPO_DUAL_STREAM": "0"}]
+VARIANTS = [{}, {"PF_PPO_GEMM": "1"}, {"PF_PPO_GEMM": "2"}, {"PF_PPO_PAIRED": "0", "PF_PPO_GEMM": "2"}, {"PF_PPO_PAIRED": "0", "PF_PPO_GEMM": "1"},
+            {"PF_PPO_FUSED_HEADS": "0"}, {"PF_PPO_FUSED_HEADS": "0", "PF_PPO_DUAL_STREAM": "0"}]
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "+".join(f"{k[7:]}={x}" for k, x in v.items()) or "default")
