@@ -26,6 +26,7 @@ import torch.distributed as dist
 NUM_ENVS = 4096
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak
 STEP_BYTES_PER_ENV = 2072      # algorithmic bytes per env-step, pointfoot_rough
 PPO_MFLOP_PER_ENV_STEP = 13.4  # 0.84 rollout + 12.5 update
 # HBM bytes per step-kernel launch come from the committed rocprofv3 PMC summary of THIS kernel (tools/pmc_traffic.py
@@ -52,6 +53,8 @@ def parse():
     p.add_argument("--num_envs", type=int, default=NUM_ENVS)
     p.add_argument("--task", type=str, default="pointfoot_rough")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--gemm", choices=["auto", "fp32", "bf16x6"], default="auto",
+                   help="dense-layer arithmetic: fp32 MFMA, fp32 by exact 3-way bf16 split on the bf16 MFMA, or by network width (default)")
     p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     p.add_argument("--single_device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     return p.parse_args()
@@ -163,6 +166,8 @@ def cpu_model():
 
 def main():
     a = parse()
+    if a.gemm != "auto":
+        os.environ["PF_PPO_GEMM"] = "1" if a.gemm == "fp32" else "2"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -258,6 +263,11 @@ def main():
         headline = a.task == "pointfoot_rough" and a.num_envs == NUM_ENVS
         dims = lambda d: "-".join(str(v) for v in d)
         kern = "pf_step_kernel<17,12,4,LeggedRobot>" if anymal else "pf_step_kernel<9,6,2,PointFoot>"
+        widest = max(max(ac.actor_dims[1:-1]), max(ac.critic_dims[1:-1]))
+        env_gemm = os.environ.get("PF_PPO_GEMM")           # set by --gemm; unset: the library picks by width (ppo_create)
+        x6 = env_gemm == "2" or (env_gemm is None and widest >= 256)
+        gemm_name = ("pf_gemm3_* (fp32 by exact three-way bf16 operand split on v_mfma_f32_32x32x16_bf16, fp32 accumulation)" if x6
+                     else "pf_gemm_* (v_mfma_f32_32x32x2_f32)")
         traffic, traffic_src = step_traffic("pf_step_kernel<17" if anymal else "pf_step_kernel<9", a.task, a.num_envs)
         out = {
             "metric": "env-steps/sec (whole node), pointfoot_rough 4096 envs/GPU" if headline else f"env-steps/sec (whole node), {a.task} {a.num_envs} envs/GPU",
@@ -268,6 +278,7 @@ def main():
                                    + ("curriculum height field 1300x2100 int16, " + (f"{env._cfg_c.num_height_points}-pt height scan, ") if rough else "plane, ")
                                    + f"DR + noise + pushes; PPO {runner.alg.num_learning_epochs} epochs x {runner.alg.num_mini_batches} "
                                    f"minibatches of {a.num_envs * T // runner.alg.num_mini_batches}, actor {dims(ac.actor_dims)} / critic {dims(ac.critic_dims)} (ELU), fp32"
+                                   + (" (dense layers: every fp32 operand split exactly into 3 bf16 terms, 6 of the 9 partial products on the bf16 MFMA, fp32 accumulation; dropped terms < 2^-23 relative)" if x6 else " (fp32 MFMA)")
                                    + (", ANYdrive actuator-network LSTM in the step kernel" if anymal else ""),
                        "parallelism": f"dp{n_gpus} (env shards, RCCL gradient all-reduce)" if n_gpus > 1 else "single GPU",
                        "finite": finite},
@@ -277,10 +288,13 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": step_ms, "bytes_per_launch": bytes_per_env * a.num_envs,
                          "note": "latency/occupancy-bound by construction (SURVEY §8d honesty note); launch_ms from HIP events on the launch stream"},
-            "roofline_ppo": {"kernel": "pf_gemm_kernel (fp32 MFMA) inside the PPO update", "bound": "mfma", "achieved": ach_tf,
+            "roofline_ppo": {"kernel": gemm_name + " inside the PPO update", "bound": "mfma", "achieved": ach_tf,
                              "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / MFMA_F32_PEAK_TFLOPS,
                              "update_ms": upd_ms, "flop_per_update": upd_flop,
-                             "note": "GEMM flops of one update / event-timed duration of the whole update phase"},
+                             "mfma_issued": ({"dtype": "bf16", "achieved": 6.0 * ach_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                              "frac": 6.0 * ach_tf / MFMA_BF16_PEAK_TFLOPS} if x6 else None),
+                             "note": "algorithmic fp32 GEMM flops of one update / event-timed duration of the whole update phase, against the fp32 "
+                                     "matrix peak; mfma_issued = the bf16 MFMA work actually issued (6 products per fp32 product) against the dense bf16 peak"},
             "phase_ms": {"env_step_launch": step_ms, "ppo_update": upd_ms, "iteration": dt / a.steps * 1e3},
         }
         if n_gpus == 1 and not a.no_cpu_baseline and not anymal:
