@@ -857,7 +857,9 @@ static int ppo_check_cfg(const PpoConfig* c) {
   if (c->num_actions < 1 || c->num_actions > 16) { pf_set_error("ppo: num_actions must be in 1..16"); return 1; }
   if (c->actor_dims[0] != c->num_obs || c->critic_dims[0] != c->num_critic_obs || c->actor_dims[c->n_actor_layers] != c->num_actions ||
       c->critic_dims[c->n_critic_layers] != 1) { pf_set_error("ppo: layer dims inconsistent with obs/action sizes"); return 1; }
-  if ((c->num_envs * c->num_steps) % c->num_mini_batches != 0) { pf_set_error("ppo: num_envs*num_steps must divide by num_mini_batches"); return 1; }
+  // rsl_rl floors the minibatch size (mini_batch_size = batch_size // num_mini_batches): the last (N*T) % num_mini_batches
+  // entries of the permutation are not used in that update
+  if (c->num_mini_batches < 1 || (long long)c->num_envs * c->num_steps < c->num_mini_batches) { pf_set_error("ppo: num_mini_batches must be in 1..num_envs*num_steps"); return 1; }
   {
     long long rows = (long long)c->num_envs * c->num_steps / c->num_mini_batches;
     long long widest = c->num_obs > c->num_critic_obs ? c->num_obs : c->num_critic_obs;

@@ -295,3 +295,24 @@ def test_two_rank_shards_match_one_full_batch_handle():
     assert shards[0].scalars[5].item() == full.scalars[5].item() == 20.0
     assert (shards[0].params - full.params).abs().max().item() <= 2e-5
     assert not torch.equal(full.params[:Pn], build(2 * n, 1, 0).params[:Pn])      # the update did move the parameters
+
+
+def test_minibatch_size_is_floored_like_rsl_rl():
+    """rsl_rl: mini_batch_size = batch_size // num_mini_batches (the remainder of the permutation is dropped); 7 envs x 5 steps
+    in 4 minibatches -> 8 samples each, 3 unused."""
+    N, T, O, P, A, hidden = 7, 5, 27, 27, 6, [64, 32]
+    alg, ref = make(N, T, O, P, A, hidden)
+    gen = torch.Generator(device="cuda:0").manual_seed(2)
+    fill_rollout(alg, ref, N, T, O, P, A, gen)
+    store = ref_store(alg)
+    perm = torch.randperm(N * T, device="cuda:0", generator=gen)
+    alg.perm.copy_(perm.to(torch.int32))
+    common._abi.check(alg._lib.ppo_minibatch_backward(alg._h, 3, alg._stream()))
+    B = (N * T) // 4
+    assert B == 8
+    mb = {k: v[perm[3 * B:4 * B].long()] for k, v in store.items()}
+    loss, kl, _, _ = ppo_ref.minibatch_loss(ref, mb, ALG["clip_param"], ALG["value_loss_coef"], ALG["entropy_coef"])
+    ref.zero_grad(); loss.backward()
+    g_ref, g = ref.flat_grad(alg.param_offsets, alg.num_params), alg.grads[:alg.num_params]
+    assert (g - g_ref).abs().max().item() <= 3e-4 * g_ref.abs().max().item() + 1e-7
+    assert alg.grads[alg.num_params + 1].item() == 8.0          # sample count in the KL tail
