@@ -294,8 +294,10 @@ __device__ __forceinline__ void pf_gemm3_body(const GemmArgs& g, const int bid, 
 // ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block and every lane receives one column (k-contiguous).
 // Row stride BM + 32 elements: the four rows of a block fall into four different 16-bank groups (conflict-free reads).
 typedef short pf_s16x4 __attribute__((ext_vector_type(4)));
-template <int BM, int BN, bool VEC_A, bool VEC_B>
+template <int BM, int BN>
 __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bid, const int nblk, unsigned char* smem) {
+  // dwordx4 loads need 16-byte aligned rows (a 27-wide observation matrix has none): decided per operand, uniform per launch
+  const bool VEC_A = ((g.lda & 3) == 0) && ((((size_t)g.A) & 15) == 0), VEC_B = ((g.ldb & 3) == 0) && ((((size_t)g.B) & 15) == 0);
   constexpr int BK = G3_BK;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int RSA = BM + 32, RSB = BN + 32;                 // row strides (bf16 elements)
@@ -312,10 +314,10 @@ __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bi
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (unsigned)g.K * (unsigned)g.lda * 4u, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (unsigned)g.K * (unsigned)g.ldb * 4u, 0x00020000);
   // 4 consecutive columns of row k; zero outside [k_end) x [ncols)
-  auto load4 = [&](__amdgpu_buffer_rsrc_t rs, int ld, int k, int col, int k_end, int ncols, auto vec) -> float4 {
+  auto load4 = [&](__amdgpu_buffer_rsrc_t rs, int ld, int k, int col, int k_end, int ncols, bool vec) -> float4 {
     const unsigned off = ((unsigned)k * (unsigned)ld + (unsigned)col) * 4u;
     const bool kv = k < k_end;
-    if constexpr (decltype(vec)::value)
+    if (vec)
       return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((kv && col < ncols) ? off : OOB), 0, 0));
     auto ld1 = [&](unsigned o, bool ok) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(ok ? o : OOB), 0, 0)); };
     return make_float4(ld1(off, kv && col < ncols), ld1(off + 4, kv && col + 1 < ncols), ld1(off + 8, kv && col + 2 < ncols), ld1(off + 12, kv && col + 3 < ncols));
@@ -341,9 +343,9 @@ __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bi
     }
     auto fetch = [&](int k0) {
 #pragma unroll
-      for (int i = 0; i < A_V4; ++i) { const int idx = tid + 256 * i; ra[i] = load4(a_rs, g.lda, k0 + idx / CA, m0 + (idx % CA) * 4, k_end, g.M, std::integral_constant<bool, VEC_A>{}); }
+      for (int i = 0; i < A_V4; ++i) { const int idx = tid + 256 * i; ra[i] = load4(a_rs, g.lda, k0 + idx / CA, m0 + (idx % CA) * 4, k_end, g.M, VEC_A); }
 #pragma unroll
-      for (int i = 0; i < B_V4; ++i) { const int idx = tid + 256 * i; rb[i] = load4(b_rs, g.ldb, k0 + idx / CB, n0 + (idx % CB) * 4, k_end, g.N, std::integral_constant<bool, VEC_B>{}); }
+      for (int i = 0; i < B_V4; ++i) { const int idx = tid + 256 * i; rb[i] = load4(b_rs, g.ldb, k0 + idx / CB, n0 + (idx % CB) * 4, k_end, g.N, VEC_B); }
     };
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of A (bias gradient): this thread's 4 columns, its rows
     auto stage = [&]() {
@@ -438,10 +440,18 @@ constexpr size_t pf_gemm3_tn_lds() {
   size_t op = (size_t)3 * G3_BK * ((BM + 32) + (BN + 32)) * 2, st = (size_t)4 * 32 * (BN / 2 + 4) * 4;
   return op > st ? op : st;
 }
-template <int BM, int BN, bool VEC_A, bool VEC_B>
+template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void pf_gemm3_tn_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[pf_gemm3_tn_lds<BM, BN>()];
-  pf_gemm3_tn_body<BM, BN, VEC_A, VEC_B>(g, (int)blockIdx.x, (int)gridDim.x, smem);
+  pf_gemm3_tn_body<BM, BN>(g, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+// the actor's and the critic's weight gradient of one layer in one launch: the pair fills the chip with half the splits each
+// (half the slab traffic, half the slab-reduction work)
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void pf_gemm3_tn_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[pf_gemm3_tn_lds<BM, BN>()];
+  if ((int)blockIdx.x < nb0) pf_gemm3_tn_body<BM, BN>(g0, (int)blockIdx.x, nb0, smem);
+  else pf_gemm3_tn_body<BM, BN>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, smem);
 }
 
 template <int BM, int BN, bool BP = false>
@@ -492,11 +502,7 @@ static inline void pf_gemm3_launch_t(const GemmArgs& g_in, int splits, hipStream
   GemmArgs g = g_in;
   const int blocks = pf_gemm3_blocks<BM, BN>(g, splits);
   if constexpr (!A_KC && !B_KC && COLSUM && EPI == GEMM_EPI_NONE) {      // weight gradient: transposed-image kernel
-    const bool va = ((g.lda & 3) == 0) && ((((size_t)g.A) & 15) == 0), vb = ((g.ldb & 3) == 0) && ((((size_t)g.B) & 15) == 0);
-    if (va && vb) hipLaunchKernelGGL((pf_gemm3_tn_kernel<BM, BN, true, true>), dim3(blocks), dim3(256), 0, s, g);
-    else if (va) hipLaunchKernelGGL((pf_gemm3_tn_kernel<BM, BN, true, false>), dim3(blocks), dim3(256), 0, s, g);
-    else if (vb) hipLaunchKernelGGL((pf_gemm3_tn_kernel<BM, BN, false, true>), dim3(blocks), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((pf_gemm3_tn_kernel<BM, BN, false, false>), dim3(blocks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((pf_gemm3_tn_kernel<BM, BN>), dim3(blocks), dim3(256), 0, s, g);
     return;
   }
   if constexpr (B_KC && !COLSUM) {
@@ -591,4 +597,28 @@ __global__ __launch_bounds__(256) void k_split_weights(SplitJobs js) {
     }
     b -= J.blocks;
   }
+}
+
+// weight-gradient pair (same tile shape for both problems): tile 0 128x128, 1 128x64, 2 64x128, 3 64x64
+static inline void pf_gemm3_tn_launch2(const GemmArgs& g0_in, int S0, const GemmArgs& g1_in, int S1, int tile, hipStream_t s) {
+  GemmArgs g0 = g0_in, g1 = g1_in;
+  auto go = [&](auto bm, auto bn) {
+    constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
+    const int nb0 = pf_gemm3_blocks<BM, BN>(g0, S0), nb1 = pf_gemm3_blocks<BM, BN>(g1, S1);
+    hipLaunchKernelGGL((pf_gemm3_tn_kernel2<BM, BN>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0);
+  };
+  using I128 = std::integral_constant<int, 128>; using I64 = std::integral_constant<int, 64>;
+  switch (tile) {
+    case 0: go(I128{}, I128{}); break;
+    case 1: go(I128{}, I64{}); break;
+    case 2: go(I64{}, I128{}); break;
+    default: go(I64{}, I64{}); break;
+  }
+}
+// split count for a problem that shares its launch with `share` problems of the same shape
+static inline void pf_gemm3_pick_split_shared(int M, int N, int K, int max_splits, int share, int* tile_out, int* splits_out) {
+  int t, S;
+  pf_gemm3_pick_split(M, N, K, max_splits, &t, &S);
+  S = (S + share - 1) / share;
+  *tile_out = t; *splits_out = S < 1 ? 1 : S;
 }

@@ -1104,7 +1104,10 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
       g[k].A = g_of(k, i); g[k].B = i == 0 ? X[k] : ws + w_h[k][i - 1]; g[k].C = ws + a->w_slabl[k][i];
       g[k].M = L.out; g[k].N = L.in; g[k].K = M; g[k].lda = L.out; g[k].ldb = L.in; g[k].ldc = L.in;
       int tile, want;
-      if (a->split3) pf_gemm3_pick_split(L.out, L.in, M, a->splits, &tile, &want);
+      // the two networks' layer-i gradients have the same shape except at the input layer (27 vs 148 columns): equal shapes
+      // share one launch and split the reduction half as often
+      const bool same = net[0]->l[i].out == net[1]->l[i].out && net[0]->l[i].in == net[1]->l[i].in;
+      if (a->split3) pf_gemm3_pick_split_shared(L.out, L.in, M, a->splits, same ? 2 : 1, &tile, &want);
       else pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
       int per = ((M + want - 1) / want + 31) / 32 * 32;
       S[k] = (M + per - 1) / per;
@@ -1113,9 +1116,12 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
       j[k] = reduce_plan(L.out * L.in + L.out, S[k], ws + a->w_slabl[k][i], G + L.w);
     }
     if (a->split3) {
-      // the actor's and the critic's weight gradients differ in shape (27 vs 148 inputs): one launch each, back to back
-      pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g[1], S[1], s, tiles3[1]);
-      pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g[0], S[0], s, tiles3[0]);
+      if (tiles3[0] == tiles3[1] && net[0]->l[i].out == net[1]->l[i].out && net[0]->l[i].in == net[1]->l[i].in)
+        pf_gemm3_tn_launch2(g[1], S[1], g[0], S[0], tiles3[0], s);
+      else {
+        pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g[1], S[1], s, tiles3[1]);
+        pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g[0], S[0], s, tiles3[0]);
+      }
     } else pf_gemm_launch2<false, false, GEMM_EPI_NONE, true>(g[1], S[1], g[0], S[0], s);
     js.j[js.n++] = j[1]; js.j[js.n++] = j[0];
   }
