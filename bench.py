@@ -53,6 +53,7 @@ def parse():
     p.add_argument("--num_envs", type=int, default=NUM_ENVS)
     p.add_argument("--task", type=str, default="pointfoot_rough")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_alt", action="store_true", help="skip the second timed loop on the fp32 MFMA kernels")
     p.add_argument("--gemm", choices=["auto", "fp32", "bf16x6"], default="auto",
                    help="dense-layer arithmetic: fp32 MFMA, fp32 by exact 3-way bf16 split on the bf16 MFMA, or by network width (default)")
     p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -238,6 +239,34 @@ def main():
     step_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_pairs]))            # one fused env-step launch
     upd_ms = float(np.mean([s.elapsed_time(e) for s, e in up_pairs]))
     finite = bool(torch.isfinite(runner.alg.params).all().item()) and bool(torch.isfinite(env.rew_buf).all().item())
+    # the same loop once more with the dense layers on the plain fp32 MFMA kernels (v_mfma_f32_32x32x2_f32), reported beside
+    # `value` so that the two arithmetic paths can be compared from one run (single GPU, default --gemm only)
+    alt = None
+    ac0 = runner.alg.actor_critic
+    if world == 1 and a.gemm == "auto" and not a.no_alt and os.environ.get("PF_PPO_GEMM") is None and \
+            max(max(ac0.actor_dims[1:-1]), max(ac0.critic_dims[1:-1])) >= 256:
+        import contextlib
+        from pointfoot_amd.envs import task_registry
+        from pointfoot_amd.utils import get_args
+        os.environ["PF_PPO_GEMM"] = "1"
+        try:
+            args2 = get_args(["--task", a.task, "--headless", "--num_envs", str(a.num_envs), "--sim_device", device, "--rl_device", device])
+            with contextlib.redirect_stdout(sys.stderr):
+                runner2, _ = task_registry.make_alg_runner(env=env, name=a.task, args=args2, log_root=None)
+            env.step = orig_step
+            o2, c2 = env.get_observations(), env.get_privileged_observations()
+            c2 = c2 if c2 is not None else o2
+            for _ in range(max(2, a.warmup // 2)):
+                o2, c2, _ = runner2.rollout(o2, c2); runner2.alg.update()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                o2, c2, _ = runner2.rollout(o2, c2); runner2.alg.update()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            alt = {"gemm": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "value": a.num_envs * T * a.steps / dt2, "ms_per_step": dt2 / a.steps * 1e3}
+        finally:
+            del os.environ["PF_PPO_GEMM"]
     lockstep = None
     if world > 1:
         # every rank must hold the same policy and have taken the same learning-rate decisions: compare a checksum of the
@@ -283,6 +312,7 @@ def main():
                        "parallelism": f"dp{n_gpus} (env shards, RCCL gradient all-reduce)" if n_gpus > 1 else "single GPU",
                        "finite": finite},
             "ranks_in_lockstep": lockstep,
+            "alt_fp32_mfma": alt,
             "roofline": {"kernel": kern + " (fused env step)", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
