@@ -363,6 +363,12 @@ int ppo_process_env_step(PpoAlg* alg, int32_t t, const float* d_rew, const uint8
  * With world_size > 1 the host all-reduces d_scalars[10..12] (sum, sumsq, count) between the two halves. */
 int ppo_compute_returns(PpoAlg* alg, const float* d_last_critic_obs, void* stream);
 int ppo_normalize_advantages(PpoAlg* alg, void* stream);
+/* Optional, once per PPO.update after d_perm has been written: brings the rollout storage into the permutation's order in
+ * one pass (rsl_rl draws one permutation per update and reuses it in every epoch), so that every ppo_minibatch_backward of
+ * this update reads contiguous slices instead of gathering its rows.  Without it each minibatch gathers for itself.  The
+ * copy is dropped by the next ppo_act(t = 0) and ppo_normalize_advantages; rewrite d_perm or the storage any other way and
+ * this has to be called again. */
+int ppo_begin_update(PpoAlg* alg, void* stream);
 /* PPO.update, one minibatch: gather, forward, KL + adaptive LR, losses, backward into d_grads. */
 int ppo_minibatch_backward(PpoAlg* alg, int32_t minibatch_index, void* stream);
 /* grad-norm clip (over the possibly all-reduced d_grads, divided by world_size) + Adam step */

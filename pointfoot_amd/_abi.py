@@ -196,9 +196,10 @@ def _bind_ppo(lib):
     lib.ppo_compute_returns.argtypes = [vp, vp, vp]
     lib.ppo_normalize_advantages.argtypes = [vp, vp]
     lib.ppo_minibatch_backward.argtypes = [vp, i32, vp]
+    lib.ppo_begin_update.argtypes = [vp, vp]
     lib.ppo_minibatch_apply.argtypes = [vp, vp]
     for fn in ("ppo_bind_buffers", "ppo_act", "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns",
-               "ppo_normalize_advantages", "ppo_minibatch_backward", "ppo_minibatch_apply"):
+               "ppo_normalize_advantages", "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_apply"):
         getattr(lib, fn).restype = i32
 
 
@@ -213,4 +214,4 @@ EXPORTED_SYMBOLS = [
     "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations",
     "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act",
     "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",
-    "ppo_minibatch_backward", "ppo_minibatch_apply"]
+    "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_apply"]

@@ -828,6 +828,8 @@ struct PpoAlg {
   int batch = 0;           // minibatch rows
   // workspace carve (floats)
   size_t w_xa, w_xc, w_act, w_oldlogp, w_oldmu, w_oldsig, w_adv, w_ret, w_oldval;
+  size_t w_perm[9];        // the nine storage arrays of an update in minibatch order (all T*N rows): ppo_begin_update
+  bool permuted = false;   // w_perm holds the current permutation (set by ppo_begin_update, dropped by the next rollout)
   size_t w_ha[PPO_MAX_LAYERS], w_hc[PPO_MAX_LAYERS];   // activations per layer output (last = head output)
   size_t w_wp[2][PPO_MAX_LAYERS], w_wtp[2][PPO_MAX_LAYERS];      // bf16 planes of W (and W^T) per hidden layer, in floats of workspace
   size_t w_dmean, w_dvalue, w_g[2][PPO_MAX_LAYERS], w_slabs[2], w_slabl[2][PPO_MAX_LAYERS + 1], w_partial, w_lastval, w_total;   // [0] actor / [1] critic scratch (run concurrently)
@@ -892,6 +894,11 @@ static void ppo_plan(PpoAlg* a) {
   a->w_xa = take(R * c.num_obs); a->w_xc = take(R * c.num_critic_obs); a->w_act = take(R * c.num_actions);
   a->w_oldlogp = take(R); a->w_oldmu = take(R * c.num_actions); a->w_oldsig = take(R * c.num_actions);
   a->w_adv = take(R); a->w_ret = take(R); a->w_oldval = take(R);
+  {
+    const size_t TN = (size_t)c.num_envs * c.num_steps;
+    const int cols[9] = {c.num_obs, c.num_critic_obs, c.num_actions, 1, c.num_actions, c.num_actions, 1, 1, 1};
+    for (int i = 0; i < 9; ++i) a->w_perm[i] = take(TN * cols[i]);
+  }
   for (int i = 0; i < a->actor.nl; ++i) a->w_ha[i] = take(R * a->actor.l[i].out);
   for (int i = 0; i < a->critic.nl; ++i) a->w_hc[i] = take(R * a->critic.l[i].out);
   a->w_dmean = take(R * c.num_actions); a->w_dvalue = take(R);
@@ -1283,7 +1290,7 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   hipStream_t s = (hipStream_t)stream;
   const int N = c.num_envs, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   float* ws = a->b.d_workspace;
-  if (t == 0) split_weights(a, s);      // parameters only change between rollouts (optimiser step, checkpoint load, broadcast)
+  if (t == 0) { split_weights(a, s); a->permuted = false; }      // parameters only change between rollouts (optimiser step, checkpoint load, broadcast); a new rollout invalidates the permuted copy of the storage
   hipStream_t s2 = a->paired ? s : ppo_fork(a, s);
   size_t tn = (size_t)t * N;
   if (a->fused_heads) {
@@ -1362,7 +1369,35 @@ int ppo_normalize_advantages(PpoAlg* a, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_normalize_advantages: buffers not bound"); return 1; }
   if (ppo_wrong_device(a)) return 1;
   size_t n = (size_t)a->cfg.num_envs * a->cfg.num_steps;
+  a->permuted = false;      // the permuted copy holds the advantages as they were
   hipLaunchKernelGGL(k_normalize, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, n, a->b.d_advantages, a->b.d_scalars);
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static void ppo_gather(PpoAlg* a, int rows, const int* perm, const size_t* dst_off, hipStream_t s) {
+  const PpoConfig& c = a->cfg;
+  const int A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
+  GatherArgs ga;
+  const float* srcs[9] = {a->b.d_obs, a->b.d_critic_obs, a->b.d_actions, a->b.d_log_prob, a->b.d_mu, a->b.d_sigma, a->b.d_advantages,
+                          a->b.d_returns, a->b.d_values};
+  const int cols[9] = {O, P, A, 1, A, A, 1, 1, 1};
+  for (int i = 0; i < 9; ++i) ga.job[i] = GatherJob{srcs[i], a->b.d_workspace + dst_off[i], cols[i]};
+  ga.njobs = 9;
+  hipLaunchKernelGGL(k_gather, dim3(1024, 9), dim3(256), 0, s, rows, perm, ga);
+}
+
+/* rsl_rl's mini_batch_generator draws ONE permutation per update and reuses it in every epoch: the storage is brought into
+ * that order once, and every minibatch of every epoch is then a contiguous slice (instead of 20 gathers per update). */
+int ppo_begin_update(PpoAlg* a, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_begin_update: buffers not bound"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
+  const long long TN = (long long)a->cfg.num_envs * a->cfg.num_steps;
+  const long long widest = std::max(a->cfg.num_obs, a->cfg.num_critic_obs);
+  if (getenv("PF_PPO_PERMUTE") && atoi(getenv("PF_PPO_PERMUTE")) == 0) { a->permuted = false; return 0; }
+  if (TN * widest >= (1ll << 31)) { a->permuted = false; return 0; }      // 32-bit gather indices: fall back to per-minibatch gathers
+  ppo_gather(a, (int)TN, a->b.d_perm, a->w_perm, (hipStream_t)stream);
+  a->permuted = true;
   PPO_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -1377,57 +1412,56 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
   const int B = a->batch, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   const int* perm = a->b.d_perm + (size_t)mb * B;
   split_weights(a, s);
+  // minibatch arrays: slices of the permuted storage (ppo_begin_update) or, without it, gathered now
+  size_t mbo[9];
   {
-    GatherArgs ga;
-    const float* srcs[9] = {a->b.d_obs, a->b.d_critic_obs, a->b.d_actions, a->b.d_log_prob, a->b.d_mu, a->b.d_sigma, a->b.d_advantages,
-                            a->b.d_returns, a->b.d_values};
-    const size_t dsts[9] = {a->w_xa, a->w_xc, a->w_act, a->w_oldlogp, a->w_oldmu, a->w_oldsig, a->w_adv, a->w_ret, a->w_oldval};
+    const size_t direct[9] = {a->w_xa, a->w_xc, a->w_act, a->w_oldlogp, a->w_oldmu, a->w_oldsig, a->w_adv, a->w_ret, a->w_oldval};
     const int cols[9] = {O, P, A, 1, A, A, 1, 1, 1};
-    for (int i = 0; i < 9; ++i) ga.job[i] = GatherJob{srcs[i], ws + dsts[i], cols[i]};
-    ga.njobs = 9;
-    hipLaunchKernelGGL(k_gather, dim3(1024, 9), dim3(256), 0, s, B, perm, ga);
+    if (a->permuted) { for (int i = 0; i < 9; ++i) mbo[i] = a->w_perm[i] + (size_t)mb * B * cols[i]; }
+    else { for (int i = 0; i < 9; ++i) mbo[i] = direct[i]; ppo_gather(a, B, perm, direct, s); }
   }
+  const size_t o_xa = mbo[0], o_xc = mbo[1], o_act = mbo[2], o_logp = mbo[3], o_mu = mbo[4], o_sig = mbo[5], o_adv = mbo[6], o_ret = mbo[7], o_val = mbo[8];
   hipStream_t s2 = a->paired ? s : ppo_fork(a, s);
   const float* stdp = a->b.d_params + a->std_off;
   const Layer& La = a->actor.l[a->actor.nl - 1];
   const Layer& Lc = a->critic.l[a->critic.nl - 1];
   if (a->fused_heads) {
     // hidden layers on the GEMM, then both heads + loss + head backward in one kernel
-    if (a->paired) mlp_forward_pair(a, ws + a->w_xa, ws + a->w_xc, B, s);
+    if (a->paired) mlp_forward_pair(a, ws + o_xa, ws + o_xc, B, s);
     else {
-      mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s, false);
-      mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s2, false);
+      mlp_forward(a, a->actor, ws + o_xa, B, a->w_ha, s, false);
+      mlp_forward(a, a->critic, ws + o_xc, B, a->w_hc, s2, false);
       ppo_join(a, s, s2);
     }
     const int nblk = (B + HEAD_ROWS - 1) / HEAD_ROWS;
     const size_t lds = sizeof(float) * ((size_t)A * La.in + Lc.in + HEAD_ROWS * (A + 1) + 4 * (A + 4));
     hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(256), lds, s, B, A, La.in, Lc.in, c.clip_param, c.value_loss_coef, c.entropy_coef,
                        c.use_clipped_value_loss, ws + a->w_ha[a->actor.nl - 2], ws + a->w_hc[a->critic.nl - 2], a->b.d_params + La.w,
-                       a->b.d_params + La.b, a->b.d_params + Lc.w, a->b.d_params + Lc.b, stdp, ws + a->w_act, ws + a->w_oldlogp,
-                       ws + a->w_oldmu, ws + a->w_oldsig, ws + a->w_adv, ws + a->w_ret, ws + a->w_oldval,
+                       a->b.d_params + La.b, a->b.d_params + Lc.w, a->b.d_params + Lc.b, stdp, ws + o_act, ws + o_logp,
+                       ws + o_mu, ws + o_sig, ws + o_adv, ws + o_ret, ws + o_val,
                        ws + a->w_g[0][a->actor.nl - 2], ws + a->w_g[1][a->critic.nl - 2],
                        ws + (a->paired ? a->w_slabl[0][a->actor.nl - 1] : a->w_slabs[0]), ws + (a->paired ? a->w_slabl[1][a->critic.nl - 1] : a->w_slabs[1]),
                        ws + a->w_partial);
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, nblk, A, B, c.entropy_coef, ws + a->w_partial, stdp,
                        a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
-    if (a->paired) mlp_backward_pair(a, ws + a->w_xa, ws + a->w_xc, B, s);
+    if (a->paired) mlp_backward_pair(a, ws + o_xa, ws + o_xc, B, s);
     else {
       s2 = ppo_fork(a, s);
-      mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, nullptr, s, 0);
-      mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, nullptr, s2, 1);
+      mlp_backward(a, a->actor, ws + o_xa, B, a->w_ha, nullptr, s, 0);
+      mlp_backward(a, a->critic, ws + o_xc, B, a->w_hc, nullptr, s2, 1);
     }
   } else {
-    mlp_forward(a, a->actor, ws + a->w_xa, B, a->w_ha, s);
-    mlp_forward(a, a->critic, ws + a->w_xc, B, a->w_hc, s2);
+    mlp_forward(a, a->actor, ws + o_xa, B, a->w_ha, s);
+    mlp_forward(a, a->critic, ws + o_xc, B, a->w_hc, s2);
     ppo_join(a, s, s2);
     hipLaunchKernelGGL(k_loss, dim3(RED_BLOCKS), dim3(256), 0, s, B, A, c.clip_param, c.value_loss_coef, c.entropy_coef, c.use_clipped_value_loss,
-                       ws + a->w_ha[a->actor.nl - 1], ws + a->w_hc[a->critic.nl - 1], stdp, ws + a->w_act, ws + a->w_oldlogp, ws + a->w_oldmu,
-                       ws + a->w_oldsig, ws + a->w_adv, ws + a->w_ret, ws + a->w_oldval, ws + a->w_dmean, ws + a->w_dvalue, ws + a->w_partial);
+                       ws + a->w_ha[a->actor.nl - 1], ws + a->w_hc[a->critic.nl - 1], stdp, ws + o_act, ws + o_logp, ws + o_mu,
+                       ws + o_sig, ws + o_adv, ws + o_ret, ws + o_val, ws + a->w_dmean, ws + a->w_dvalue, ws + a->w_partial);
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, RED_BLOCKS, A, B, c.entropy_coef, ws + a->w_partial, stdp,
                        a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
     s2 = ppo_fork(a, s);
-    mlp_backward(a, a->actor, ws + a->w_xa, B, a->w_ha, ws + a->w_dmean, s, 0);
-    mlp_backward(a, a->critic, ws + a->w_xc, B, a->w_hc, ws + a->w_dvalue, s2, 1);
+    mlp_backward(a, a->actor, ws + o_xa, B, a->w_ha, ws + a->w_dmean, s, 0);
+    mlp_backward(a, a->critic, ws + o_xc, B, a->w_hc, ws + a->w_dvalue, s2, 1);
   }
   ppo_join(a, s, s2);
   PPO_HIP_OK(hipGetLastError());

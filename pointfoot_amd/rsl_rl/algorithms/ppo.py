@@ -153,6 +153,7 @@ class PPO:
         # rsl_rl mini_batch_generator: one randperm per update, reused by every epoch
         self.perm.copy_(torch.randperm(n, device=self.device).to(torch.int32))
         self.scalars[SC_VLOSS:SC_SLOSS + 1] = 0.0
+        _abi.check(lib.ppo_begin_update(self._h, self._stream()), lib)      # storage into permutation order, once for all epochs
         for _epoch in range(self.num_learning_epochs):
             for mb in range(self.num_mini_batches):
                 _abi.check(lib.ppo_minibatch_backward(self._h, mb, self._stream()), lib)

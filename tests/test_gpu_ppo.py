@@ -155,6 +155,16 @@ def test_full_size_minibatch_gradient():
     g1 = g.clone()
     common._abi.check(alg._lib.ppo_minibatch_backward(alg._h, 2, alg._stream()))
     assert torch.equal(g1, alg.grads[:alg.num_params])
+    # storage permuted once (ppo_begin_update): every minibatch is a slice of it, same bits as gathering per minibatch
+    common._abi.check(alg._lib.ppo_begin_update(alg._h, alg._stream()))
+    common._abi.check(alg._lib.ppo_minibatch_backward(alg._h, 2, alg._stream()))
+    assert torch.equal(g1, alg.grads[:alg.num_params])
+    common._abi.check(alg._lib.ppo_minibatch_backward(alg._h, 0, alg._stream()))
+    g0 = alg.grads[:alg.num_params].clone()
+    common._abi.check(alg._lib.ppo_normalize_advantages(alg._h, alg._stream()))      # drops the copy
+    st.advantages.copy_(store["advantages"].view(T, N, 1))
+    common._abi.check(alg._lib.ppo_minibatch_backward(alg._h, 0, alg._stream()))
+    assert torch.equal(g0, alg.grads[:alg.num_params])
 
 
 def test_gemm_shapes_against_torch():
