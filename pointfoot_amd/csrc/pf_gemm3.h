@@ -13,20 +13,38 @@
 // Same three arrangements and epilogues as pf_gemm.h (FWD / BWD_X / BWD_W with split-K slabs and fused bias column sums).
 // Tiling: 256 threads = 2x2 wavefronts, block tile BM x BN in {64,128}^2, BK = 32; a wave owns (BM/2) x (BN/2) as 32x32
 // MFMA tiles.  Operands are fetched as fp32 (buffer loads, out-of-range -> 0), split in registers and staged in LDS as three
-// bf16 planes per operand, row-major over the tile's m (n) index, 32 k per row + 8 pad (80-byte rows: the 16 lanes of a
-// ds_read_b128 phase hit 64 distinct banks); lane l of an MFMA reads row l & 31, k = 8 (l >> 5) .. +7 of a 16-wide k-step:
-// one ds_read_b128 per plane per 32x32 operand tile per k-step.
+// bf16 planes per operand, row-major over the tile's m (n) index, 32 k = 64 bytes per row with the 16-byte chunks XOR-swizzled
+// (g3_soff: conflict-free b128 stores and reads); lane l of an MFMA reads row l & 31, k = 8 (l >> 5) .. +7 of a 16-wide
+// k-step: one ds_read_b128 per plane per 32x32 operand tile per k-step.
 #pragma once
 #include "pf_gemm.h"
 
 typedef __bf16 pf_bf16x8 __attribute__((ext_vector_type(8)));
 
+// Diagnostic builds only (tools/gemm_ablate.hip): -DG3_ABLATE=mask removes one ingredient of the main loop at a time to see
+// what the loop's time is made of (results are wrong by construction).  1 MFMAs, 2 operand split, 4 LDS stores, 8 in-loop
+// global loads, 16 fragment reads, 32 barriers.  The library is built with 0 and contains none of it.
+#ifndef G3_ABLATE
+#define G3_ABLATE 0
+#endif
+#define G3_KEEP(x) asm volatile("" ::"v"(x))
 constexpr int G3_BK = 32;
-constexpr int G3_RS = 40;      // LDS row stride in bf16 elements
+constexpr int G3_RS = 32;      // LDS row stride in bf16 elements: one 64-byte row per 32-wide k-slice, no padding
+// A row holds four 16-byte chunks (8 k each); chunk c of row r lives at chunk position c ^ ((r >> 2) & 3).  A 16-lane phase
+// of a ds_read_b128 takes the same chunk of 16 consecutive rows: rows r, r+4, r+8, r+12 (same bank group unswizzled) land in
+// four different positions, so the phase covers all 64 banks once; a 16-lane phase of the staging ds_write_b128 covers four
+// whole rows.  No padding: 36 KB for a 128 x 64 tile, so LDS never limits the number of resident workgroups.
+__device__ __forceinline__ int g3_soff(int row, int chunk) { return row * G3_RS + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
 // exact split of 4 consecutive-k fp32 values of one row into three packed-bf16 quads
 __device__ __forceinline__ void g3_split4(const float4& v, uint2& p0, uint2& p1, uint2& p2) {
   const float x[4] = {v.x, v.y, v.z, v.w};
+  if constexpr ((G3_ABLATE & 2) != 0) {
+    p0 = make_uint2(__builtin_bit_cast(uint32_t, v.x), __builtin_bit_cast(uint32_t, v.y));
+    p1 = make_uint2(__builtin_bit_cast(uint32_t, v.z), __builtin_bit_cast(uint32_t, v.w));
+    p2 = p0;
+    return;
+  }
   uint32_t h[4], m[4], l[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -41,6 +59,14 @@ __device__ __forceinline__ void g3_split4(const float4& v, uint2& p0, uint2& p1,
   p0 = make_uint2(pk(h[0], h[1]), pk(h[2], h[3]));
   p1 = make_uint2(pk(m[0], m[1]), pk(m[2], m[3]));
   p2 = make_uint2(pk(l[0], l[1]), pk(l[2], l[3]));
+}
+
+// 8 consecutive-k fp32 values -> one 16-byte chunk per plane
+__device__ __forceinline__ void g3_split8(const float4& v0, const float4& v1, uint4& p0, uint4& p1, uint4& p2) {
+  uint2 a0, a1, a2, b0, b1, b2;
+  g3_split4(v0, a0, a1, a2);
+  g3_split4(v1, b0, b1, b2);
+  p0 = make_uint4(a0.x, a0.y, b0.x, b0.y); p1 = make_uint4(a1.x, a1.y, b1.x, b1.y); p2 = make_uint4(a2.x, a2.y, b2.x, b2.y);
 }
 
 // Write-out of a block tile's accumulators (shared by the row-image and the transposed-image kernels).  C/D layout of a
@@ -171,7 +197,8 @@ __device__ __forceinline__ void pf_gemm3_body(const GemmArgs& g, const int bid, 
 #pragma unroll
       for (int i = 0; i < A_V4; ++i) {
         const int idx = tid + 256 * i;
-        if (A_KC) ra[i] = load_kc(a_rs, g.lda, m0 + idx / (BK / 4), k0 + (idx % (BK / 4)) * 4, g.M, k_end);
+        // k-contiguous operand: float4 2t and 2t + 1 are the two halves of 16-byte chunk (T & 3) of row T >> 2, T = tid + 256 t
+        if (A_KC) ra[i] = load_kc(a_rs, g.lda, m0 + ((tid + 256 * (i >> 1)) >> 2), k0 + ((tid + 256 * (i >> 1)) & 3) * 8 + 4 * (i & 1), g.M, k_end);
         else ra[i] = load_mc(a_rs, g.lda, k0 + (idx / BM) * 4, m0 + idx % BM, k_end, g.M);
       }
       if constexpr (BP) {
@@ -186,40 +213,65 @@ __device__ __forceinline__ void pf_gemm3_body(const GemmArgs& g, const int bid, 
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
           const int idx = tid + 256 * i;
-          if (B_KC) rb[i] = load_kc(b_rs, g.ldb, n0 + idx / (BK / 4), k0 + (idx % (BK / 4)) * 4, g.N, k_end);
+          if (B_KC) rb[i] = load_kc(b_rs, g.ldb, n0 + ((tid + 256 * (i >> 1)) >> 2), k0 + ((tid + 256 * (i >> 1)) & 3) * 8 + 4 * (i & 1), g.N, k_end);
           else rb[i] = load_mc(b_rs, g.ldb, k0 + (idx / BN) * 4, n0 + idx % BN, k_end, g.N);
         }
       }
     };
+    // m-contiguous operand: a thread holds 4 consecutive k (half a chunk) of one row
     auto put = [&](uint16_t* S, int plane_elems, int row, int q, const float4& v) {
       uint2 p0, p1, p2;
       g3_split4(v, p0, p1, p2);
-      uint16_t* d = S + row * RS + 4 * q;
+      uint16_t* d = S + g3_soff(row, q >> 1) + 4 * (q & 1);
+      if constexpr ((G3_ABLATE & 4) != 0) { G3_KEEP(p0.x); G3_KEEP(p0.y); G3_KEEP(p1.x); G3_KEEP(p1.y); G3_KEEP(p2.x); G3_KEEP(p2.y); return; }
       *reinterpret_cast<uint2*>(d) = p0;
       *reinterpret_cast<uint2*>(d + plane_elems) = p1;
       *reinterpret_cast<uint2*>(d + 2 * plane_elems) = p2;
+    };
+    auto put8 = [&](uint16_t* S, int plane_elems, int t, const float4& v0, const float4& v1) {
+      uint4 p0, p1, p2;
+      g3_split8(v0, v1, p0, p1, p2);
+      const int T = tid + 256 * t;
+      uint16_t* d = S + g3_soff(T >> 2, T & 3);
+      if constexpr ((G3_ABLATE & 4) != 0) {
+        G3_KEEP(p0.x); G3_KEEP(p0.y); G3_KEEP(p0.z); G3_KEEP(p0.w); G3_KEEP(p1.x); G3_KEEP(p1.y); G3_KEEP(p1.z); G3_KEEP(p1.w);
+        G3_KEEP(p2.x); G3_KEEP(p2.y); G3_KEEP(p2.z); G3_KEEP(p2.w);
+        return;
+      }
+      *reinterpret_cast<uint4*>(d) = p0;
+      *reinterpret_cast<uint4*>(d + plane_elems) = p1;
+      *reinterpret_cast<uint4*>(d + 2 * plane_elems) = p2;
     };
     float csum[A_V4];     // COLSUM (A is m-contiguous): this thread's partial column sums of A over the split's rows
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) csum[i] = 0.0f;
     auto stage = [&]() {
+      if constexpr (A_KC) {
 #pragma unroll
-      for (int i = 0; i < A_V4; ++i) {
-        const int idx = tid + 256 * i;
-        if (A_KC) put(As, PLANE_A, idx / (BK / 4), idx % (BK / 4), ra[i]); else put(As, PLANE_A, idx % BM, idx / BM, ra[i]);
-        if (COLSUM) csum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+        for (int t = 0; t < A_V4 / 2; ++t) put8(As, PLANE_A, t, ra[2 * t], ra[2 * t + 1]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+          const int idx = tid + 256 * i;
+          put(As, PLANE_A, idx % BM, idx / BM, ra[i]);
+          if (COLSUM) csum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+        }
       }
       if constexpr (BP) {
 #pragma unroll
         for (int i = 0; i < B_P8; ++i) {
           const int idx = tid + 256 * i, c = idx & 3, r = (idx >> 2) % BN, p = idx / (4 * BN);
-          *reinterpret_cast<uint4*>(Bs + p * PLANE_B + r * RS + 8 * c) = rbp[i];
+          if constexpr ((G3_ABLATE & 4) != 0) { G3_KEEP(rbp[i].x); G3_KEEP(rbp[i].y); G3_KEEP(rbp[i].z); G3_KEEP(rbp[i].w); continue; }
+          *reinterpret_cast<uint4*>(Bs + p * PLANE_B + g3_soff(r, c)) = rbp[i];
         }
+      } else if constexpr (B_KC) {
+#pragma unroll
+        for (int t = 0; t < B_V4 / 2; ++t) put8(Bs, PLANE_B, t, rb[2 * t], rb[2 * t + 1]);
       } else {
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
           const int idx = tid + 256 * i;
-          if (B_KC) put(Bs, PLANE_B, idx / (BK / 4), idx % (BK / 4), rb[i]); else put(Bs, PLANE_B, idx % BN, idx / BN, rb[i]);
+          put(Bs, PLANE_B, idx % BN, idx / BN, rb[i]);
         }
       }
     };
@@ -233,24 +285,39 @@ __device__ __forceinline__ void pf_gemm3_body(const GemmArgs& g, const int bid, 
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const int arow = wr * (BM / 2) + (lane & 31), bcol = wc * (BN / 2) + (lane & 31), kh = lane >> 5;
     fetch(k_begin);
+    pf_bf16x8 a[TM][3], b[TN][3];
+    auto frags = [&](int kk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[i][p] = *reinterpret_cast<const pf_bf16x8*>(As + p * PLANE_A + g3_soff(arow + 32 * i, 2 * kk + kh));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[j][p] = *reinterpret_cast<const pf_bf16x8*>(Bs + p * PLANE_B + g3_soff(bcol + 32 * j, 2 * kk + kh));
+    };
+    if constexpr ((G3_ABLATE & 16) != 0) frags(0);
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-      __syncthreads();          // previous k-slice (or the previous tile's write-out) fully consumed
+      if constexpr ((G3_ABLATE & 32) == 0) __syncthreads();          // previous k-slice (or the previous tile's write-out) fully consumed
       stage();
-      __syncthreads();
-      if (k0 + BK < k_end) fetch(k0 + BK);
+      if constexpr ((G3_ABLATE & 32) == 0) __syncthreads();
+      if constexpr ((G3_ABLATE & 8) == 0) { if (k0 + BK < k_end) fetch(k0 + BK); }
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
-        pf_bf16x8 a[TM][3], b[TN][3];
+        if constexpr ((G3_ABLATE & 16) == 0) frags(kk);
+        if constexpr ((G3_ABLATE & 1) != 0) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
-            a[i][p] = *reinterpret_cast<const pf_bf16x8*>(As + p * PLANE_A + (arow + 32 * i) * RS + kk * 16 + kh * 8);
+            for (int p = 0; p < 3; ++p) G3_KEEP(a[i][p]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+          for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
-            b[j][p] = *reinterpret_cast<const pf_bf16x8*>(Bs + p * PLANE_B + (bcol + 32 * j) * RS + kk * 16 + kh * 8);
+            for (int p = 0; p < 3; ++p) G3_KEEP(b[j][p]);
+          continue;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -463,13 +530,13 @@ constexpr size_t pf_gemm3_lds() {
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool VEC, bool BP = false>
-__global__ __launch_bounds__(256, 2) void pf_gemm3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64 ? 4 : 2)) void pf_gemm3_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[pf_gemm3_lds<BM, BN, BP>()];
   pf_gemm3_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC, BP>(g, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 // two problems of the same arrangement in one launch (the actor's and the critic's layer i)
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, bool COLSUM, bool VEC0, bool VEC1, bool BP = false>
-__global__ __launch_bounds__(256, 2) void pf_gemm3_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64 ? 4 : 2)) void pf_gemm3_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[pf_gemm3_lds<BM, BN, BP>()];
   if ((int)blockIdx.x < nb0) pf_gemm3_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC0, BP>(g0, (int)blockIdx.x, nb0, smem);
   else pf_gemm3_body<BM, BN, A_KC, B_KC, EPI, COLSUM, VEC1, BP>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, smem);
