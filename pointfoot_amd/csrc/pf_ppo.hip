@@ -532,6 +532,9 @@ __global__ void k_loss(int B, int A, float clip, float vcoef, float ecoef, int c
 //            head weight / bias gradient partials of the block's rows -> slabs (reduced by k_reduce_slabs*)
 // partial[block][0..A+4) as k_loss.  Same formulas and summation structure as the separate kernels.
 constexpr int HEAD_ROWS = 32;
+// AT: compile-time number of actions (6: biped, 12: quadrupeds) or 16 = any A <= 16 with run-time masks; with the exact count
+// the per-action loops carry no dead iterations (the kernel is VALU-bound: 2.1 k VALU instructions per wave with AT = 16).
+template <int AT>
 __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, float clip, float vcoef, float ecoef, int clipped_value,
                                                const float* __restrict__ Ha, const float* __restrict__ Hc,
                                                const float* __restrict__ Wa, const float* __restrict__ ba,
@@ -555,16 +558,16 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
   const bool rv = row < B;
   const float invB = 1.0f / (float)B;
   // ---- phase 1: heads forward (8 lanes per row; dwordx4 row reads when the widths allow)
-  float mu[16], val = 0.0f;
+  float mu[AT], val = 0.0f;
 #pragma unroll
-  for (int o = 0; o < 16; ++o) mu[o] = 0.0f;
+  for (int o = 0; o < AT; ++o) mu[o] = 0.0f;
   if (rv) {
     if (((Ka | Kc) & 3) == 0) {
       const float4* xr = reinterpret_cast<const float4*>(Ha + (size_t)row * Ka);
       for (int k4 = lane8; k4 < (Ka >> 2); k4 += 8) {
         float4 x = xr[k4];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) if (o < A) {
+        for (int o = 0; o < AT; ++o) if (AT < 16 || o < A) {
           float4 w = *reinterpret_cast<const float4*>(&sWa[o * Ka + 4 * k4]);
           mu[o] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
         }
@@ -578,13 +581,13 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
       for (int k = lane8; k < Ka; k += 8) {
         float x = Ha[(size_t)row * Ka + k];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) if (o < A) mu[o] += x * sWa[o * Ka + k];
+        for (int o = 0; o < AT; ++o) if (AT < 16 || o < A) mu[o] += x * sWa[o * Ka + k];
       }
       for (int k = lane8; k < Kc; k += 8) val += Hc[(size_t)row * Kc + k] * sWc[k];
     }
   }
 #pragma unroll
-  for (int o = 0; o < 16; ++o) if (o < A) {
+  for (int o = 0; o < AT; ++o) if (AT < 16 || o < A) {
     float v = mu[o];
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
     mu[o] = v + ba[o];
@@ -598,12 +601,12 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
     const int i = rv ? row : 0;
     float lp = 0.0f, kls = 0.0f, ens = 0.0f, dmu_own[2] = {0.0f, 0.0f}, dsg_own[2] = {0.0f, 0.0f};
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < (AT > 8 ? 2 : 1); ++kk) {
       const int k = lane8 + 8 * kk;
       if (rv && k < A) {
         float m = 0.0f;
 #pragma unroll
-        for (int o = 0; o < 16; ++o) if (o == k) m = mu[o];       // register select (mu[] is indexed by constants only)
+        for (int o = 0; o < AT; ++o) if (o == k) m = mu[o];       // register select (mu[] is indexed by constants only)
         const float sg = stdp[k], a = act[(size_t)i * A + k];
         const float d = a - m;
         lp += -0.5f * (d * d) / (sg * sg) - logf(sg) - 0.91893853320467274178f;
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
       }
     } else if (lane8 == 0) sD[lr * (A + 1) + A] = 0.0f;            // rows past the batch contribute nothing
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < (AT > 8 ? 2 : 1); ++kk) {
       const int k = lane8 + 8 * kk;
       if (k < A) { sD[lr * (A + 1) + k] = g_lp * dmu_own[kk]; dstd_own[kk] = g_lp * dsg_own[kk]; }
     }
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
     };
     // dL/dstd[k]: lanes with lane8 == k (mod 8) of the wave's 8 rows -> shuffle over the row bits only
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < (AT > 8 ? 2 : 1); ++kk) {
       float t = dstd_own[kk];
       t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
       const int k = lane8 + 8 * kk;
@@ -677,9 +680,9 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
   if (threadIdx.x < 128) {
     float* sl_out = slabsA + (size_t)blockIdx.x * ((size_t)A * Ka + A);
     for (int k = threadIdx.x; k < Ka; k += 128) {
-      float w[16], dw[16];
+      float w[AT], dw[AT];
 #pragma unroll
-      for (int o = 0; o < 16; ++o) { w[o] = o < A ? sWa[o * Ka + k] : 0.0f; dw[o] = 0.0f; }
+      for (int o = 0; o < AT; ++o) { w[o] = (AT < 16 || o < A) ? sWa[o * Ka + k] : 0.0f; dw[o] = 0.0f; }
       int r = 0;
       for (; r + 8 <= nr; r += 8) {
         float h[8], g[8];
@@ -688,18 +691,18 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
-          for (int o = 0; o < 16; ++o) if (o < A) { float d = sD[(r + u) * (A + 1) + o]; g[u] += d * w[o]; dw[o] += d * h[u]; }
+          for (int o = 0; o < AT; ++o) if (AT < 16 || o < A) { float d = sD[(r + u) * (A + 1) + o]; g[u] += d * w[o]; dw[o] += d * h[u]; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) Ga[(size_t)(r0 + r + u) * Ka + k] = g[u] * (h[u] > 0.0f ? 1.0f : h[u] + 1.0f);
       }
       for (; r < nr; ++r) {
         float h = Ha[(size_t)(r0 + r) * Ka + k], g = 0.0f;
 #pragma unroll
-        for (int o = 0; o < 16; ++o) if (o < A) { float d = sD[r * (A + 1) + o]; g += d * w[o]; dw[o] += d * h; }
+        for (int o = 0; o < AT; ++o) if (AT < 16 || o < A) { float d = sD[r * (A + 1) + o]; g += d * w[o]; dw[o] += d * h; }
         Ga[(size_t)(r0 + r) * Ka + k] = g * (h > 0.0f ? 1.0f : h + 1.0f);
       }
 #pragma unroll
-      for (int o = 0; o < 16; ++o) if (o < A) sl_out[(size_t)o * Ka + k] = dw[o];
+      for (int o = 0; o < AT; ++o) if (AT < 16 || o < A) sl_out[(size_t)o * Ka + k] = dw[o];
     }
     if (threadIdx.x < A) {        // bias gradient = column sums of dL/dmean over the block's rows
       float db = 0.0f;
@@ -1435,7 +1438,8 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
     }
     const int nblk = (B + HEAD_ROWS - 1) / HEAD_ROWS;
     const size_t lds = sizeof(float) * ((size_t)A * La.in + Lc.in + HEAD_ROWS * (A + 1) + 4 * (A + 4));
-    hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(256), lds, s, B, A, La.in, Lc.in, c.clip_param, c.value_loss_coef, c.entropy_coef,
+    auto kh = A == 6 ? k_heads<6> : A == 12 ? k_heads<12> : k_heads<16>;
+    hipLaunchKernelGGL(kh, dim3(nblk), dim3(256), lds, s, B, A, La.in, Lc.in, c.clip_param, c.value_loss_coef, c.entropy_coef,
                        c.use_clipped_value_loss, ws + a->w_ha[a->actor.nl - 2], ws + a->w_hc[a->critic.nl - 2], a->b.d_params + La.w,
                        a->b.d_params + La.b, a->b.d_params + Lc.w, a->b.d_params + Lc.b, stdp, ws + o_act, ws + o_logp,
                        ws + o_mu, ws + o_sig, ws + o_adv, ws + o_ret, ws + o_val,
