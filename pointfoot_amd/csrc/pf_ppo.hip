@@ -365,14 +365,14 @@ static inline void reduce_slabs2(const ReduceJob& j0, const ReduceJob& j1, hipSt
 }
 
 // ------------------------------------------------------------------------------------- minibatch gather
-struct GatherJob { const float* src; float* dst; int cols; };
+struct GatherJob { const float* src; float* dst; int cols, dst_ld; };      // dst rows are dst_ld >= cols wide, zero padded
 struct GatherArgs { GatherJob job[9]; int njobs; };
 // rsl_rl mini_batch_generator: rows perm[b] of every storage array -> contiguous minibatch arrays (one launch)
 __global__ void k_gather(int B, const int* __restrict__ perm, GatherArgs ga) {
   const GatherJob j = ga.job[blockIdx.y];
   // 32-bit index arithmetic (the host checks B * cols < 2^31): a 64-bit divide per element made this kernel ALU-bound
   const unsigned stride = gridDim.x * blockDim.x;
-  if ((j.cols & 3) == 0 && (((size_t)j.src | (size_t)j.dst) & 15) == 0) {      // rows are whole float4s (critic obs: 148 = 37 x 4)
+  if (j.dst_ld == j.cols && (j.cols & 3) == 0 && (((size_t)j.src | (size_t)j.dst) & 15) == 0) {      // rows are whole float4s (critic obs: 148 = 37 x 4)
     const unsigned c4n = (unsigned)j.cols >> 2, n4 = (unsigned)B * c4n;
     const float4* src = reinterpret_cast<const float4*>(j.src);
     float4* dst = reinterpret_cast<float4*>(j.dst);
@@ -382,10 +382,10 @@ __global__ void k_gather(int B, const int* __restrict__ perm, GatherArgs ga) {
     }
     return;
   }
-  const unsigned cols = (unsigned)j.cols, n = (unsigned)B * cols;
+  const unsigned cols = (unsigned)j.cols, ld = (unsigned)j.dst_ld, n = (unsigned)B * ld;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    unsigned r = i / cols, c = i - r * cols;
-    j.dst[i] = j.src[(size_t)perm[r] * cols + c];
+    unsigned r = i / ld, c = i - r * ld;
+    j.dst[i] = c < cols ? j.src[(size_t)perm[r] * cols + c] : 0.0f;
   }
 }
 
@@ -831,6 +831,7 @@ struct PpoAlg {
   int batch = 0;           // minibatch rows
   // workspace carve (floats)
   size_t w_xa, w_xc, w_act, w_oldlogp, w_oldmu, w_oldsig, w_adv, w_ret, w_oldval;
+  int ld_xa = 0, ld_xc = 0;   // row strides of the minibatch observation copies: widths rounded up to 4 floats (16-byte rows: dwordx4 loads)
   size_t w_perm[9];        // the nine storage arrays of an update in minibatch order (all T*N rows): ppo_begin_update
   bool permuted = false;   // w_perm holds the current permutation (set by ppo_begin_update, dropped by the next rollout)
   size_t w_ha[PPO_MAX_LAYERS], w_hc[PPO_MAX_LAYERS];   // activations per layer output (last = head output)
@@ -894,12 +895,13 @@ static void ppo_plan(PpoAlg* a) {
   a->splits = 128;
   size_t R = a->max_rows, w = 0;
   auto take = [&](size_t n) { size_t at = w; w += (n + 63) & ~(size_t)63; return at; };
-  a->w_xa = take(R * c.num_obs); a->w_xc = take(R * c.num_critic_obs); a->w_act = take(R * c.num_actions);
+  a->ld_xa = (c.num_obs + 3) & ~3; a->ld_xc = (c.num_critic_obs + 3) & ~3;
+  a->w_xa = take(R * a->ld_xa); a->w_xc = take(R * a->ld_xc); a->w_act = take(R * c.num_actions);
   a->w_oldlogp = take(R); a->w_oldmu = take(R * c.num_actions); a->w_oldsig = take(R * c.num_actions);
   a->w_adv = take(R); a->w_ret = take(R); a->w_oldval = take(R);
   {
     const size_t TN = (size_t)c.num_envs * c.num_steps;
-    const int cols[9] = {c.num_obs, c.num_critic_obs, c.num_actions, 1, c.num_actions, c.num_actions, 1, 1, 1};
+    const int cols[9] = {a->ld_xa, a->ld_xc, c.num_actions, 1, c.num_actions, c.num_actions, 1, 1, 1};
     for (int i = 0; i < 9; ++i) a->w_perm[i] = take(TN * cols[i]);
   }
   for (int i = 0; i < a->actor.nl; ++i) a->w_ha[i] = take(R * a->actor.l[i].out);
@@ -970,8 +972,16 @@ static void use_planes(PpoAlg* a, GemmArgs& g, int net, int layer, bool transpos
   else { g.Bp = reinterpret_cast<const unsigned short*>(a->b.d_workspace + a->w_wtp[net][layer]); g.ldbp = outp; g.bplane = (long long)L.in * outp; }
 }
 
+// First layer on a zero-padded input copy (row stride ldx, a multiple of 4): with the weights as bf16 planes (rows zero padded
+// to 8) the reduction simply runs over the padded width and every A load is a dwordx4; the fp32 B operand has no padding, so
+// that path keeps K and only takes the stride.
+static void pad_input(GemmArgs& g, int ldx) {
+  g.lda = ldx;
+  if (g.Bp && ldx <= g.ldbp) g.K = ldx;
+}
 // forward through one MLP: X[M, in0] -> activations; hidden layers on the MFMA GEMM (bias + ELU fused), head on the thin kernel
-static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, hipStream_t s, bool with_head = true) {
+// ldx: row stride of X when it is a zero-padded copy (0: rows are exactly in0 wide)
+static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, hipStream_t s, bool with_head = true, int ldx = 0) {
   float* ws = a->b.d_workspace; const float* P = a->b.d_params;
   const float* in = X;
   for (int i = 0; i < n.nl; ++i) {
@@ -986,6 +996,7 @@ static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const si
       GemmArgs g{};
       g.A = in; g.B = P + L.w; g.C = out; g.M = M; g.N = L.out; g.K = L.in; g.lda = L.in; g.ldb = L.in; g.ldc = L.out; g.bias = P + L.b;
       use_planes(a, g, &n == &a->actor ? 0 : 1, i, false);
+      if (i == 0 && ldx > 0) pad_input(g, ldx);
       if (a->split3) pf_gemm3_launch<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
       else pf_gemm_auto<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
     }
@@ -995,7 +1006,7 @@ static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const si
 
 // backward through one MLP given dHead[M, out_last]; writes weight/bias gradients into d_grads
 // (dHead == nullptr: k_heads already wrote g[last-1] and the head's gradient slabs; only their reduction is left)
-static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, const float* dHead, hipStream_t s, int set) {
+static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const size_t* w_h, const float* dHead, hipStream_t s, int set, int ldx = 0) {
   float* ws = a->b.d_workspace; const float* P = a->b.d_params; float* G = a->b.d_grads;
   float* slabs = ws + a->w_slabs[set];
   const int last = n.nl - 1;
@@ -1033,7 +1044,7 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
     // (deterministic slab reduce straight into the flat gradient: W then b)
     {
       GemmArgs g{};
-      g.A = gcur; g.B = in; g.C = slabs; g.M = L.out; g.N = L.in; g.K = M; g.lda = L.out; g.ldb = L.in; g.ldc = L.in;
+      g.A = gcur; g.B = in; g.C = slabs; g.M = L.out; g.N = L.in; g.K = M; g.lda = L.out; g.ldb = (i == 0 && ldx > 0) ? ldx : L.in; g.ldc = L.in;
       int tile, want;
       if (a->split3) pf_gemm3_pick_split(L.out, L.in, M, a->splits, &tile, &want);
       else pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
@@ -1068,18 +1079,21 @@ static GemmArgs fwd_args(PpoAlg* a, const Net& n, int i, const float* in, const 
   g.bias = a->b.d_params + L.b;
   return g;
 }
-static void mlp_forward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s) {
+static void mlp_forward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s, int ldxa = 0, int ldxc = 0) {
   float* ws = a->b.d_workspace;
   const float *ina = Xa, *inc = Xc;
   for (int i = 0; i + 1 < a->actor.nl; ++i) {       // hidden layers; the heads run in k_heads / k_act_heads
     GemmArgs ga = fwd_args(a, a->actor, i, ina, a->w_ha, M), gc = fwd_args(a, a->critic, i, inc, a->w_hc, M);
     use_planes(a, ga, 0, i, false); use_planes(a, gc, 1, i, false);
+    if (i == 0 && ldxa > 0) pad_input(ga, ldxa);
+    if (i == 0 && ldxc > 0) pad_input(gc, ldxc);
     if (a->split3) pf_gemm3_launch2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);
     else pf_gemm_auto2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);     // the larger problem (critic) first
     ina = ws + a->w_ha[i]; inc = ws + a->w_hc[i];
   }
 }
-static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s) {
+static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s, int ldxa = 0, int ldxc = 0) {
+  const int ldx[2] = {ldxa, ldxc};
   float* ws = a->b.d_workspace; const float* P = a->b.d_params; float* G = a->b.d_grads;
   const Net* net[2] = {&a->actor, &a->critic};
   const size_t* w_h[2] = {a->w_ha, a->w_hc};
@@ -1112,7 +1126,7 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
       const Layer& L = net[k]->l[i];
       g[k] = GemmArgs{};
       g[k].A = g_of(k, i); g[k].B = i == 0 ? X[k] : ws + w_h[k][i - 1]; g[k].C = ws + a->w_slabl[k][i];
-      g[k].M = L.out; g[k].N = L.in; g[k].K = M; g[k].lda = L.out; g[k].ldb = L.in; g[k].ldc = L.in;
+      g[k].M = L.out; g[k].N = L.in; g[k].K = M; g[k].lda = L.out; g[k].ldb = (i == 0 && ldx[k] > 0) ? ldx[k] : L.in; g[k].ldc = L.in;
       int tile, want;
       // the two networks' layer-i gradients have the same shape except at the input layer (27 vs 148 columns): equal shapes
       // share one launch and split the reduction half as often
@@ -1385,7 +1399,8 @@ static void ppo_gather(PpoAlg* a, int rows, const int* perm, const size_t* dst_o
   const float* srcs[9] = {a->b.d_obs, a->b.d_critic_obs, a->b.d_actions, a->b.d_log_prob, a->b.d_mu, a->b.d_sigma, a->b.d_advantages,
                           a->b.d_returns, a->b.d_values};
   const int cols[9] = {O, P, A, 1, A, A, 1, 1, 1};
-  for (int i = 0; i < 9; ++i) ga.job[i] = GatherJob{srcs[i], a->b.d_workspace + dst_off[i], cols[i]};
+  const int lds[9] = {a->ld_xa, a->ld_xc, A, 1, A, A, 1, 1, 1};
+  for (int i = 0; i < 9; ++i) ga.job[i] = GatherJob{srcs[i], a->b.d_workspace + dst_off[i], cols[i], lds[i]};
   ga.njobs = 9;
   hipLaunchKernelGGL(k_gather, dim3(1024, 9), dim3(256), 0, s, rows, perm, ga);
 }
@@ -1396,7 +1411,7 @@ int ppo_begin_update(PpoAlg* a, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_begin_update: buffers not bound"); return 1; }
   if (ppo_wrong_device(a)) return 1;
   const long long TN = (long long)a->cfg.num_envs * a->cfg.num_steps;
-  const long long widest = std::max(a->cfg.num_obs, a->cfg.num_critic_obs);
+  const long long widest = std::max(a->ld_xa, a->ld_xc);
   if (getenv("PF_PPO_PERMUTE") && atoi(getenv("PF_PPO_PERMUTE")) == 0) { a->permuted = false; return 0; }
   if (TN * widest >= (1ll << 31)) { a->permuted = false; return 0; }      // 32-bit gather indices: fall back to per-minibatch gathers
   ppo_gather(a, (int)TN, a->b.d_perm, a->w_perm, (hipStream_t)stream);
@@ -1419,7 +1434,7 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
   size_t mbo[9];
   {
     const size_t direct[9] = {a->w_xa, a->w_xc, a->w_act, a->w_oldlogp, a->w_oldmu, a->w_oldsig, a->w_adv, a->w_ret, a->w_oldval};
-    const int cols[9] = {O, P, A, 1, A, A, 1, 1, 1};
+    const int cols[9] = {a->ld_xa, a->ld_xc, A, 1, A, A, 1, 1, 1};
     if (a->permuted) { for (int i = 0; i < 9; ++i) mbo[i] = a->w_perm[i] + (size_t)mb * B * cols[i]; }
     else { for (int i = 0; i < 9; ++i) mbo[i] = direct[i]; ppo_gather(a, B, perm, direct, s); }
   }
@@ -1430,10 +1445,10 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
   const Layer& Lc = a->critic.l[a->critic.nl - 1];
   if (a->fused_heads) {
     // hidden layers on the GEMM, then both heads + loss + head backward in one kernel
-    if (a->paired) mlp_forward_pair(a, ws + o_xa, ws + o_xc, B, s);
+    if (a->paired) mlp_forward_pair(a, ws + o_xa, ws + o_xc, B, s, a->ld_xa, a->ld_xc);
     else {
-      mlp_forward(a, a->actor, ws + o_xa, B, a->w_ha, s, false);
-      mlp_forward(a, a->critic, ws + o_xc, B, a->w_hc, s2, false);
+      mlp_forward(a, a->actor, ws + o_xa, B, a->w_ha, s, false, a->ld_xa);
+      mlp_forward(a, a->critic, ws + o_xc, B, a->w_hc, s2, false, a->ld_xc);
       ppo_join(a, s, s2);
     }
     const int nblk = (B + HEAD_ROWS - 1) / HEAD_ROWS;
@@ -1448,15 +1463,15 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
                        ws + a->w_partial);
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, nblk, A, B, c.entropy_coef, ws + a->w_partial, stdp,
                        a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
-    if (a->paired) mlp_backward_pair(a, ws + o_xa, ws + o_xc, B, s);
+    if (a->paired) mlp_backward_pair(a, ws + o_xa, ws + o_xc, B, s, a->ld_xa, a->ld_xc);
     else {
       s2 = ppo_fork(a, s);
-      mlp_backward(a, a->actor, ws + o_xa, B, a->w_ha, nullptr, s, 0);
-      mlp_backward(a, a->critic, ws + o_xc, B, a->w_hc, nullptr, s2, 1);
+      mlp_backward(a, a->actor, ws + o_xa, B, a->w_ha, nullptr, s, 0, a->ld_xa);
+      mlp_backward(a, a->critic, ws + o_xc, B, a->w_hc, nullptr, s2, 1, a->ld_xc);
     }
   } else {
-    mlp_forward(a, a->actor, ws + o_xa, B, a->w_ha, s);
-    mlp_forward(a, a->critic, ws + o_xc, B, a->w_hc, s2);
+    mlp_forward(a, a->actor, ws + o_xa, B, a->w_ha, s, true, a->ld_xa);
+    mlp_forward(a, a->critic, ws + o_xc, B, a->w_hc, s2, true, a->ld_xc);
     ppo_join(a, s, s2);
     hipLaunchKernelGGL(k_loss, dim3(RED_BLOCKS), dim3(256), 0, s, B, A, c.clip_param, c.value_loss_coef, c.entropy_coef, c.use_clipped_value_loss,
                        ws + a->w_ha[a->actor.nl - 1], ws + a->w_hc[a->critic.nl - 1], stdp, ws + o_act, ws + o_logp, ws + o_mu,
@@ -1464,8 +1479,8 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, RED_BLOCKS, A, B, c.entropy_coef, ws + a->w_partial, stdp,
                        a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars);
     s2 = ppo_fork(a, s);
-    mlp_backward(a, a->actor, ws + o_xa, B, a->w_ha, ws + a->w_dmean, s, 0);
-    mlp_backward(a, a->critic, ws + o_xc, B, a->w_hc, ws + a->w_dvalue, s2, 1);
+    mlp_backward(a, a->actor, ws + o_xa, B, a->w_ha, ws + a->w_dmean, s, 0, a->ld_xa);
+    mlp_backward(a, a->critic, ws + o_xc, B, a->w_hc, ws + a->w_dvalue, s2, 1, a->ld_xc);
   }
   ppo_join(a, s, s2);
   PPO_HIP_OK(hipGetLastError());
