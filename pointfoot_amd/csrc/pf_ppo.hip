@@ -1130,27 +1130,36 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
       else pf_gemm_auto2<true, false, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
     }
     // dW_i, db_i as split-K slabs, then the deterministic slab reduce straight into the flat gradient
-    GemmArgs g[2]; int S[2], tiles3[2] = {0, 0}; ReduceJob j[2];
+    GemmArgs g[2]; int S[2], tiles3[2] = {0, 0}, want[2]; ReduceJob j[2];
+    // the two networks' layer-i gradients have the same shape except at the input layer (27 vs 148 columns): both go out in
+    // ONE launch either way.  Equal shapes split the reduction half as often; unequal ones take a common tile (128 x 64, or
+    // 64 x 64 for narrow layers) and share ~512 workgroups in proportion to their tile counts.
+    const bool same = net[0]->l[i].out == net[1]->l[i].out && net[0]->l[i].in == net[1]->l[i].in;
+    for (int k = 0; k < 2; ++k) {
+      const Layer& L = net[k]->l[i];
+      if (a->split3) pf_gemm3_pick_split_shared(L.out, L.in, M, a->splits, same ? 2 : 1, &tiles3[k], &want[k]);
+      else pf_pick_split(L.out, L.in, M, a->splits, &tiles3[k], &want[k]);
+    }
+    if (a->split3 && tiles3[0] != tiles3[1]) {
+      const int tc = std::min(net[0]->l[i].out, net[1]->l[i].out) > 64 ? 1 : 3, bm = tc == 1 ? 128 : 64, bn = 64;
+      int tot = 0;
+      for (int k = 0; k < 2; ++k) tot += ((net[k]->l[i].out + bm - 1) / bm) * ((net[k]->l[i].in + bn - 1) / bn);
+      int Sc = std::max(1, std::min(std::min(want[0], want[1]), (512 + tot - 1) / tot));      // never more slabs than either layer's buffer holds
+      while (Sc > 1 && (M + Sc - 1) / Sc < 128) --Sc;
+      tiles3[0] = tiles3[1] = tc; want[0] = want[1] = Sc;
+    }
     for (int k = 0; k < 2; ++k) {
       const Layer& L = net[k]->l[i];
       g[k] = GemmArgs{};
       g[k].A = g_of(k, i); g[k].B = i == 0 ? X[k] : ws + w_h[k][i - 1]; g[k].C = ws + a->w_slabl[k][i];
       g[k].M = L.out; g[k].N = L.in; g[k].K = M; g[k].lda = L.out; g[k].ldb = (i == 0 && ldx[k] > 0) ? ldx[k] : L.in; g[k].ldc = L.in;
-      int tile, want;
-      // the two networks' layer-i gradients have the same shape except at the input layer (27 vs 148 columns): equal shapes
-      // share one launch and split the reduction half as often
-      const bool same = net[0]->l[i].out == net[1]->l[i].out && net[0]->l[i].in == net[1]->l[i].in;
-      if (a->split3) pf_gemm3_pick_split_shared(L.out, L.in, M, a->splits, same ? 2 : 1, &tile, &want);
-      else pf_pick_split(L.out, L.in, M, a->splits, &tile, &want);
-      int per = ((M + want - 1) / want + 31) / 32 * 32;
+      int per = ((M + want[k] - 1) / want[k] + 31) / 32 * 32;
       S[k] = (M + per - 1) / per;
       g[k].k_per_split = per;
-      tiles3[k] = tile;
       j[k] = reduce_plan(L.out * L.in + L.out, S[k], ws + a->w_slabl[k][i], G + L.w);
     }
     if (a->split3) {
-      if (tiles3[0] == tiles3[1] && net[0]->l[i].out == net[1]->l[i].out && net[0]->l[i].in == net[1]->l[i].in)
-        pf_gemm3_tn_launch2(g[1], S[1], g[0], S[0], tiles3[0], s);
+      if (tiles3[0] == tiles3[1]) pf_gemm3_tn_launch2(g[1], S[1], g[0], S[0], tiles3[0], s);
       else {
         pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g[1], S[1], s, tiles3[1]);
         pf_gemm3_launch<false, false, GEMM_EPI_NONE, true>(g[0], S[0], s, tiles3[0]);
