@@ -696,6 +696,8 @@ void compute_observations(const Ctx& x, int env, float* S, const float* heights)
   for (int k = 0; k < nd; ++k) o[w++] = S[L.dof_vel + k] * c.obs_scale_dof_vel;
   for (int k = 0; k < na; ++k) o[w++] = S[L.actions + k];
   for (int i = 0; i < 3; ++i) o[w++] = S[L.commands + i] * c.commands_scale[i];
+  // cfg.terrain.measure_heights_actor (point_foot.py:361-373): the measurements follow, num_obs = 27 + 121
+  for (int j = 0; w < no && j < c.num_height_points; ++j) o[w++] = clipf((S[L.root + 2] - 0.5f) - heights[j], -1.0f, 1.0f) * c.obs_scale_height;
   float* obs = x.b->d_obs + (size_t)env * no;
   float* priv = x.b->d_priv ? x.b->d_priv + (size_t)env * np_ : nullptr;
   for (int i = 0; i < no; ++i) {
@@ -707,7 +709,7 @@ void compute_observations(const Ctx& x, int env, float* S, const float* heights)
     obs[i] = clipf(v, -c.clip_obs, c.clip_obs);
     if (priv) priv[i] = clipf(pv, -c.clip_obs, c.clip_obs);
   }
-  if (priv && c.measure_heights) {
+  if (priv && c.measure_heights && np_ > no) {      // critic-only heights; with actor heights the copy above already holds them (:340-345)
     for (int j = 0; j < c.num_height_points; ++j) {   // :367-373
       float hgt = clipf((S[L.root + 2] - 0.5f) - heights[j], -1.0f, 1.0f) * c.obs_scale_height;
       if (c.add_noise) hgt += (2.0f * rnd(x, env, L.r_priv + j) - 1.0f) * c.priv_height_noise;

@@ -112,6 +112,10 @@ static int pf_validate(const PfModel* m, const PfConfig* c) {
     return 1;
   }
   int want_obs = inst == 0 ? 9 + 3 * m->nd : 12 + 3 * m->nd + c->num_height_points;
+  // PointFoot with cfg.terrain.measure_heights_actor: the height measurements follow the proprioceptive terms, and a privileged
+  // buffer, if there is one, has the same layout (the reference adds the actor's noise buffer to its front)
+  if (inst == 0 && c->num_obs == want_obs + c->num_height_points && c->measure_heights &&
+      (c->num_priv_obs == 0 || c->num_priv_obs == c->num_obs)) want_obs = c->num_obs;
   if (m->nsph > (inst == 0 ? PF_KSPH : PF_KSPH_QUAD) || c->num_obs > PF_MAX_OBS || c->num_height_points > PF_MAX_HPTS ||
       c->num_rewards >= PF_MAX_REWARDS || c->num_actions != m->nd || c->num_obs != want_obs) {
     pf_set_error("pf_create: configuration outside the compiled limits");

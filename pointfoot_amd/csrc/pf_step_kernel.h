@@ -1111,6 +1111,11 @@ struct PfKernel {
       }
       return;
     }
+    // proprioceptive block (:375-382), then -- cfg.terrain.measure_heights_actor (:361, num_obs = 27 + 121) -- the height
+    // measurements.  The privileged buffer repeats these entries with the SAME noise draws (:340-345: the actor's noise buffer
+    // is concatenated in front of the privileged extras), so the copy below covers it; critic-only heights (num_priv_obs >
+    // num_obs) are the separate block with noise of their own.
+    const int nprop = 6 + 2 * ND + na + 3;
     PF_LANES(i, no) {
       float v;
       if (i < 3) v = S[LC::base_ang_vel + i] * c.obs_scale_ang_vel;
@@ -1118,13 +1123,14 @@ struct PfKernel {
       else if (i < 6 + ND) v = (S[LC::dof_pos + i - 6] - c.default_dof_pos[i - 6]) * c.obs_scale_dof_pos;
       else if (i < 6 + 2 * ND) v = S[LC::dof_vel + i - 6 - ND] * c.obs_scale_dof_vel;
       else if (i < 6 + 2 * ND + na) v = S[LC::actions + i - 6 - 2 * ND];
-      else { int k = i - 6 - 2 * ND - na; v = S[LC::commands + k] * c.commands_scale[k]; }
+      else if (i < nprop) { int k = i - 6 - 2 * ND - na; v = S[LC::commands + k] * c.commands_scale[k]; }
+      else v = pf_clip((S[LC::root + 2] - 0.5f) - hts[i - nprop], -1.0f, 1.0f) * c.obs_scale_height;
       if (c.add_noise) v += (2.0f * rnd(c, L, inj, env, step, L.r_obs + i) - 1.0f) * c.obs_noise_vec[i];
       v = pf_clip(v, -c.clip_obs, c.clip_obs);
       B.d_obs[(size_t)env * no + i] = v;
       if (B.d_priv) B.d_priv[(size_t)env * np_ + i] = v;
     }
-    if (B.d_priv && c.measure_heights) {
+    if (B.d_priv && c.measure_heights && np_ > no) {
       PF_LANES(j, c.num_height_points) {    // :367-373
         float h = pf_clip((S[LC::root + 2] - 0.5f) - hts[j], -1.0f, 1.0f) * c.obs_scale_height;
         if (c.add_noise) h += (2.0f * rnd(c, L, inj, env, step, L.r_priv + j) - 1.0f) * c.priv_height_noise;

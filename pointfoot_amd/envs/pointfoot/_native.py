@@ -191,7 +191,16 @@ def build_config(cfg, model, info, sim_params, num_envs, *, env_index_base=0, nu
     else:
         c.measure_heights = int(bool(cfg.terrain.measure_heights_critic or cfg.terrain.measure_heights_actor))
         if cfg.terrain.measure_heights_actor:
-            raise NotImplementedError("measure_heights_actor=True is not built (both PointFoot tasks use critic-only heights)")
+            # point_foot.py:361: the 121 measurements follow the 27 proprioceptive terms; :340-345 adds the actor's noise buffer
+            # to the front of the privileged buffer, which only lines up when that buffer has the same layout or is absent
+            npts = len(cfg.terrain.measured_points_x) * len(cfg.terrain.measured_points_y)
+            nprop = 9 + 2 * nd + cfg.env.num_actions
+            if cfg.env.num_propriceptive_obs != nprop + npts:
+                raise RuntimeError(f"obs_buf size ({nprop + npts}) does not match num_obs ({cfg.env.num_propriceptive_obs})")   # :363-365
+            npriv = cfg.env.num_privileged_obs
+            if npriv is not None and not (cfg.terrain.measure_heights_critic and npriv == cfg.env.num_propriceptive_obs):
+                raise NotImplementedError("measure_heights_actor with a privileged buffer of a different layout "
+                                          "(the reference's own noise concatenation, point_foot.py:340-345, fails on it)")
     px, py = cfg.terrain.measured_points_x, cfg.terrain.measured_points_y
     H = len(px) * len(py) if c.measure_heights else 0
     if H > _abi.PF_MAX_HPTS:

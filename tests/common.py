@@ -65,7 +65,10 @@ def make_cfg(task, num_envs, control_type="P", add_noise=True):
         cfg.control.control_type = control_type
         cfg.noise.add_noise = add_noise
         return cfg
-    cfg = PointFootRoughCfg() if task == "rough" else PointFootFlatCfg()
+    cfg = PointFootRoughCfg() if task.startswith("rough") else PointFootFlatCfg()
+    if task == "rough_hactor":      # point_foot.py:361: height measurements in the actor's observations too
+        cfg.terrain.measure_heights_actor = True
+        cfg.env.num_propriceptive_obs = 27 + len(cfg.terrain.measured_points_x) * len(cfg.terrain.measured_points_y)
     cfg.env.num_envs = num_envs
     cfg.control.control_type = control_type
     cfg.noise.add_noise = add_noise
@@ -164,7 +167,7 @@ def sim_from_golden(g, task, control_type="P", add_noise=True):
     import synth
     n = g["init_root"].shape[0]
     cfg = make_cfg(task, n, control_type, add_noise)
-    rough = task == "rough"
+    rough = task.startswith("rough")
     hf = synth.synth_heightfield() if rough else None
     to = g["terrain_origins"] if rough else None
     sim = HostSim(cfg, n, hf=hf, terrain_origins=to, mean_base_mass=float(g["base_mass"].mean(dtype=np.float32)))
@@ -196,7 +199,7 @@ def inject_from_golden(g, t, sim, keep):
     n = sim.n
     p = f"s{t}"
     rnd = np.zeros((n, L.rand_floats), np.float32)
-    rnd[:, L.r_obs:L.r_obs + 27] = g[p + "_r_obs"]
+    rnd[:, L.r_obs:L.r_obs + g[p + "_r_obs"].shape[1]] = g[p + "_r_obs"]
     rp = g[p + "_r_priv"]
     if rp.shape[1]:
         rnd[:, L.r_priv:L.r_priv + rp.shape[1]] = rp

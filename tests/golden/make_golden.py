@@ -184,10 +184,13 @@ def build_env(task, n, rng_seed, control_type="P"):
     from legged_gym.envs.pointfoot.mixed_terrain.pointfoot_rough_config import PointFootRoughCfg
     from legged_gym.envs.pointfoot.flat.pointfoot_flat_config import PointFootFlatCfg
 
-    cfg = PointFootRoughCfg() if task == "rough" else PointFootFlatCfg()
+    cfg = PointFootRoughCfg() if task.startswith("rough") else PointFootFlatCfg()
     cfg.env.num_envs = n
     cfg.control.control_type = control_type
-    rough = task == "rough"
+    if task == "rough_hactor":      # point_foot.py:361: height measurements in the actor's observations too
+        cfg.terrain.measure_heights_actor = True
+        cfg.env.num_propriceptive_obs = 27 + len(cfg.terrain.measured_points_x) * len(cfg.terrain.measured_points_y)
+    rough = task.startswith("rough")
     e = object.__new__(PointFoot)
     e.terminate = None
     e.cfg = cfg
@@ -301,7 +304,7 @@ def scatter_rows(n, ids, t, width):
 
 def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at=2):
     e, cfg = build_env(task, n, seed, control_type)
-    rough = task == "rough"
+    rough = task.startswith("rough")
     rl = RandLog(seed)
     torch.rand = rl.rand
     torch.rand_like = rl.rand_like
@@ -405,8 +408,8 @@ def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at
         r_dof = np.zeros((n, 6), np.float32)
         r_xy = np.zeros((n, 2), np.float32)
         r_vel = np.zeros((n, 6), np.float32)
-        r_obs = np.zeros((n, 27), np.float32)
-        r_priv = np.zeros((n, e.num_privileged_obs - 27), np.float32)
+        r_obs = np.zeros((n, e.num_obs), np.float32)
+        r_priv = np.zeros((n, e.num_privileged_obs - e.num_obs), np.float32)
         pushed = e.cfg.domain_rand.push_robots and (e.common_step_counter % e.cfg.domain_rand.push_interval == 0)
         if pushed:
             kind, shape, tt = calls[ci]; ci += 1
@@ -429,10 +432,10 @@ def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at
             r_vel = scatter_rows(n, ids, tt, 6)
         if add_noise:
             kind, shape, tt = calls[ci]; ci += 1
-            assert kind == "rand_like" and shape == (n, 27)
+            assert kind == "rand_like" and shape == (n, e.num_obs)
             r_obs = tt.numpy().copy()
             kind, shape, tt = calls[ci]; ci += 1
-            assert kind == "rand_like" and shape == (n, e.num_privileged_obs - 27)
+            assert kind == "rand_like" and shape == (n, e.num_privileged_obs - e.num_obs)
             r_priv = tt.numpy().copy()
         assert ci == len(calls), (ci, len(calls))
         p = f"s{t}"
@@ -723,12 +726,16 @@ def main():
         print("wrote terrain_grid.npz")
         return
     jobs = [("flat", 64, 6, 1, "P", True), ("rough", 64, 6, 2, "P", True),
-            ("flat", 16, 2, 3, "V", False), ("flat", 16, 2, 4, "T", False)]
+            ("flat", 16, 2, 3, "V", False), ("flat", 16, 2, 4, "T", False), ("rough_hactor", 16, 3, 5, "P", True)]
+    if len(sys.argv) > 1 and sys.argv[1] == "hactor":        # only the heights-in-actor-observations fixture
+        jobs = jobs[-1:]
     for task, n, steps, seed, ct, noise in jobs:
         out = run_sequence(task, n, steps, seed, ct, noise)
         fn = os.path.join(HERE, f"pf_{task}_{ct}_n{n}.npz")
         np.savez_compressed(fn, **out)
         print("wrote", fn, os.path.getsize(fn), "bytes; rewards:", list(out["reward_names"]))
+    if len(sys.argv) > 1 and sys.argv[1] == "hactor":
+        return
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc_vectors())
     out = run_sequence_lr(32, 5, 6, anymal_model())
     fn = os.path.join(HERE, "lr_anymal_c_rough_n32.npz")

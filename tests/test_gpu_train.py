@@ -260,3 +260,42 @@ def test_command_curriculum_widens_ranges():
         assert tuple(env.command_ranges["lin_vel_x"]) == (lo1, hi1)
     finally:
         env_cfg.commands.curriculum, env_cfg.commands.ranges.lin_vel_x, env_cfg.commands.max_curriculum = saved[0], saved[1], saved[2]
+
+
+def test_measure_heights_actor_env_and_training_iteration():
+    """cfg.terrain.measure_heights_actor (point_foot.py:361-373, :683-687): the 121 height measurements follow the 27
+    proprioceptive terms in the ACTOR's observations (num_obs 148); the privileged buffer carries the same entries with the
+    same noise draws (:340-345).  The step is pinned by the reference-generated fixture pf_rough_hactor_P_n16; here the class
+    surface and one PPO iteration on the 148-wide actor."""
+    from pointfoot_amd.envs import task_registry
+    env_cfg, train_cfg = task_registry.get_cfgs("pointfoot_rough")
+    saved = (env_cfg.terrain.measure_heights_actor, env_cfg.env.num_propriceptive_obs)
+    try:
+        env_cfg.terrain.measure_heights_actor = True
+        env_cfg.env.num_propriceptive_obs = 27 + 121
+        n = 64
+        env, cfg = task_registry.make_env("pointfoot_rough", args=_args("pointfoot_rough", n), env_cfg=env_cfg)
+        assert env.num_obs == 148 and env.num_privileged_obs == 148
+        obs, priv = env.reset()
+        assert obs.shape == (n, 148) and priv.shape == (n, 148)
+        a = torch.zeros(n, 6, device=obs.device)
+        _ = env.measured_heights                             # first read binds the output; the next step fills it
+        for _ in range(3):
+            obs, priv, rew, done, extras = env.step(a)
+        torch.cuda.synchronize()
+        assert torch.isfinite(obs).all() and torch.equal(obs, priv)
+        h = torch.clip(env.root_states[:, 2:3] - 0.5 - env.measured_heights, -1.0, 1.0) * cfg.normalization.obs_scales.height_measurements
+        noise = cfg.noise.noise_scales.height_measurements * cfg.noise.noise_level * cfg.normalization.obs_scales.height_measurements
+        keep = ~done.bool()                                  # reset envs keep the pre-reset terms (stale-obs quirk, App. D.6)
+        assert float((obs[keep, 27:] - h[keep]).abs().max()) <= noise + 1e-5
+        runner, _ = task_registry.make_alg_runner(env, "pointfoot_rough", args=_args("pointfoot_rough", n), log_root=None)
+        assert runner.alg.actor_critic.actor[0].in_features == 148
+        runner.learn(num_learning_iterations=1, init_at_random_ep_len=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(runner.alg.params).all()
+        # the reference refuses a buffer width that does not match (:363-365)
+        env_cfg.env.num_propriceptive_obs = 27
+        with pytest.raises(RuntimeError, match="does not match num_obs"):
+            task_registry.make_env("pointfoot_rough", args=_args("pointfoot_rough", n), env_cfg=env_cfg)
+    finally:
+        env_cfg.terrain.measure_heights_actor, env_cfg.env.num_propriceptive_obs = saved
