@@ -1,6 +1,6 @@
 // Diagnostic: what is the bf16-split GEMM's main loop made of?  Built once per -DG3_ABLATE mask by tools/gemm_ablate.sh; every
 // build runs the same shape and prints its time.  Results of an ablated build are wrong by construction -- only times are read.
-//   gemm_ablate MODE M N K TILE BP       MODE 0 FWD (x W^T + b, ELU), 1 BWD_X;  TILE 0 128x128, 1 128x64, 3 64x64;  BP 1: B as bf16 planes
+//   gemm_ablate MODE M N K TILE BP [ZEROS]      MODE 0 FWD (x W^T + b, ELU), 1 BWD_X;  TILE 0 128x128, 1 128x64, 3 64x64;  BP 1: B as bf16 planes
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -14,11 +14,12 @@ int main(int argc, char** argv) {
   OK(hipMalloc(&A, (size_t)M * K * 4)); OK(hipMalloc(&B, (size_t)N * K * 4)); OK(hipMalloc(&Cm, (size_t)M * N * 4));
   OK(hipMalloc(&bias, (size_t)N * 4)); OK(hipMalloc(&H, (size_t)M * N * 4)); OK(hipMalloc(&Bp, (size_t)3 * N * ldbp * 2));
   std::vector<float> h((size_t)M * K);
-  for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+  const bool zeros = argc > 7 && atoi(argv[7]) != 0;      // zero operands: same instruction stream, less switching power
+  for (auto& v : h) v = zeros ? 0.0f : (float)rand() / RAND_MAX - 0.5f;
   OK(hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
   OK(hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
   OK(hipMemset(bias, 0, N * 4)); OK(hipMemcpy(H, h.data(), (size_t)std::min((size_t)M * N, h.size()) * 4, hipMemcpyHostToDevice));
-  OK(hipMemset(Bp, 0x3c, (size_t)3 * N * ldbp * 2));
+  OK(hipMemset(Bp, zeros ? 0 : 0x3c, (size_t)3 * N * ldbp * 2));
   GemmArgs g{};
   g.A = A; g.C = Cm; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.bias = bias; g.H = H; g.ldh = N;
   if (mode == 0) { g.B = B; g.ldb = K; } else { g.B = B; g.ldb = N; }      // FWD: B [N][K]; BWD_X: B [K][N]
@@ -36,6 +37,6 @@ int main(int argc, char** argv) {
   for (int i = 0; i < iters; ++i) launch();
   OK(hipEventRecord(e1, 0)); OK(hipEventSynchronize(e1));
   float ms; OK(hipEventElapsedTime(&ms, e0, e1));
-  printf("ablate %2d mode %d M=%d N=%d K=%d tile %d bp %d: %.1f us\n", G3_ABLATE, mode, M, N, K, tile, bp, ms * 1000.0f / iters);
+  printf("ablate %2d mode %d M=%d N=%d K=%d tile %d bp %d%s: %.1f us\n", G3_ABLATE, mode, M, N, K, tile, bp, zeros ? " zeros" : "", ms * 1000.0f / iters);
   return 0;
 }
