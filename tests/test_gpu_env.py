@@ -58,9 +58,23 @@ def _physics_sim(task, n, seed=0, noise=True):
 
 def _same_decisions(sim, ref):
     """Envs whose discrete decisions agree between the HIP kernel and the oracle for this step: reset flag, active
-    contact set and active joint-limit rows of every substep (PfBuffers.d_contact_set).  A flip of one of these is a
-    different (equally valid) branch of a discontinuous map; everything else has to agree to 1e-4."""
-    return (ref.reset == sim.reset) & (ref.contact_set == sim.contact_set).all(axis=(1, 2))
+    contact set and active joint-limit rows of every substep (PfBuffers.d_contact_set), feet-contact flags.  A flip of one of
+    these is a different (equally valid) branch of a discontinuous map; everything else has to agree to 1e-4."""
+    same = (ref.reset == sim.reset) & (ref.contact_set == sim.contact_set).all(axis=(1, 2))
+    # the feet-state machine thresholds the contact force at 1 N (point_foot.py:_compute_feet_states): a force within rounding
+    # of the threshold flips contact_filt / first_contact, and with it the discrete reward terms (0.02 per flag) -- the same
+    # kind of decision, taken one stage later (seen once in 49 152 env-steps after a change of compiler flags)
+    if hasattr(sim, "L") and sim.c.env_kind == common._abi.PF_KIND_POINTFOOT:
+        for nm in ("contact_filt", "first_contact", "last_contacts"):
+            same &= ((sim.f(nm, 2) != 0) == (ref.f(nm, 2) != 0)).all(axis=1)
+        # ... and the reward terms threshold the same forces at 0.1 N: _reward_no_fly (feet, z component) and
+        # _reward_collision (norm, penalised bodies): a foot grazing the ground with 0.12 N sits on that line
+        L = sim.L
+        cs = sim.state[:, L.contact_forces:L.contact_forces + 27].reshape(-1, 9, 3)
+        cr = ref.state[:, L.contact_forces:L.contact_forces + 27].reshape(-1, 9, 3)
+        same &= ((np.linalg.norm(cs, axis=2) > 0.1) == (np.linalg.norm(cr, axis=2) > 0.1)).all(axis=1)
+        same &= ((cs[:, :, 2] > 0.1) == (cr[:, :, 2] > 0.1)).all(axis=1)
+    return same
 
 
 KAPPA = 8.0

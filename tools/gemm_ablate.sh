@@ -7,7 +7,7 @@ mkdir -p tools/_build
 MASKS="0 1 2 4 6 8 16 32 63 62"
 if [ "$1" = build ]; then
   for m in $MASKS; do
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -DG3_ABLATE=$m -o tools/_build/gemm_ablate_$m tools/gemm_ablate.hip &
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -DG3_ABLATE=$m -o tools/_build/gemm_ablate_$m tools/gemm_ablate.hip &
     if (( $(jobs -r | wc -l) >= 5 )); then wait -n; fi
   done
   wait
