@@ -19,6 +19,17 @@
 
 // ------------------------------------------------------------------------------------ small math
 PF_DEV float pf_clip(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// 1 / x for the solver's pivots, normalisations and friction ratios: v_rcp_f32 (1 ulp) + one Newton step instead of the IEEE
+// division sequence (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup: 48 of them were 12 % of a substep's VALU work).
+// Within an ulp of the quotient; the host build of the step program divides.
+PF_DEV float pf_rcp(float x) {
+#if defined(PF_HOST_EMU)
+  return 1.0f / x;
+#else
+  const float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+#endif
+}
 PF_DEV void pf_cross(const float* a, const float* b, float* o) {
   float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   o[0] = x; o[1] = y; o[2] = z;
@@ -295,7 +306,7 @@ struct PfKernel {
     *h = (1.0f - tx) * ((1.0f - ty) * E00 + ty * E01) + tx * ((1.0f - ty) * E10 + ty * E11);
     float dhdx = ((1.0f - ty) * (E10 - E00) + ty * (E11 - E01)) / hsc;
     float dhdy = ((1.0f - tx) * (E01 - E00) + tx * (E11 - E10)) / hsc;
-    float inv = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
+    float inv = pf_rcp(sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f));
     n[0] = -dhdx * inv; n[1] = -dhdy * inv; n[2] = inv;
     if (steep) {
       // 0: x-far (normal -x), 1: x-near (+x), 2: y-far (-y), 3: y-near (+y)
@@ -309,7 +320,7 @@ struct PfKernel {
         const float len = sqrtf(gap[f] * gap[f] + dz * dz);
         const float dist = len - rad;
         const bool take = (top[f] - bot[f] > thr) && dist < best;
-        const float il = 1.0f / fmaxf(len, 1e-9f);
+        const float il = pf_rcp(fmaxf(len, 1e-9f));
         const bool deg = !(len > 1e-9f);
         best = take ? dist : best; bf = take ? f : bf;
         bh = take ? (deg ? 1.0f : gap[f] * il) : bh; bz = take ? (deg ? 0.0f : dz * il) : bz;
@@ -635,7 +646,7 @@ struct PfKernel {
 #pragma unroll
         for (int t = 0; t < j; ++t) d -= Lr[lt(j, t)] * Lr[lt(j, t)];
         d = sqrtf(fmaxf(d, 1e-12f));
-        const float di = 1.0f / d;
+        const float di = pf_rcp(d);
         dv[j] = di;
 #pragma unroll
         for (int i = j + 1; i < NV; ++i) {
@@ -660,7 +671,7 @@ struct PfKernel {
 #pragma unroll
         for (int t = 0; t < j; ++t) d -= pj[t] * pj[t];
         d = sqrtf(fmaxf(d, 1e-12f));
-        const float di = 1.0f / d;
+        const float di = pf_rcp(d);
         float sacc = r[j];
 #pragma unroll
         for (int t = 0; t < j; ++t) sacc -= r[t] * pj[t];
@@ -679,7 +690,7 @@ struct PfKernel {
         float d = sh.M[j][j];
         for (int t = 0; t < j; ++t) d -= sh.M[j][t] * sh.M[j][t];
         d = sqrtf(fmaxf(d, 1e-12f));
-        float di = 1.0f / d;
+        float di = pf_rcp(d);
         PF_LANES(ii, NV - j - 1) {
           int i = j + 1 + ii;
           float s = sh.M[i][j];
@@ -720,7 +731,7 @@ struct PfKernel {
         const float len = sqrtf(pf_dot3(v, v)), rb = m.sph_radius[b0];
         const float dist = len - m.sph_radius[a0] - rb;
         const bool ok = len > 1e-9f;
-        const float il = 1.0f / fmaxf(len, 1e-9f);
+        const float il = pf_rcp(fmaxf(len, 1e-9f));
         float n[3] = {ok ? v[0] * il : 0.0f, ok ? v[1] * il : 1.0f, ok ? v[2] * il : 0.0f};
         sh.pd[p] = dist;
         for (int t = 0; t < 3; ++t) { sh.pn[p][t] = n[t]; sh.px[p][t] = c2[t] + (rb + 0.5f * dist) * n[t]; }
@@ -787,7 +798,7 @@ struct PfKernel {
       }
       float ref[3] = {fabsf(n[0]) < 0.9f ? 1.0f : 0.0f, fabsf(n[0]) < 0.9f ? 0.0f : 1.0f, 0.0f};
       float t1[3]; pf_cross(n, ref, t1);
-      float il = 1.0f / sqrtf(pf_dot3(t1, t1));
+      float il = pf_rcp(sqrtf(pf_dot3(t1, t1)));
       for (int t = 0; t < 3; ++t) t1[t] *= il;
       float t2[3]; pf_cross(n, t1, t2);
       float dd[3];
@@ -924,7 +935,7 @@ struct PfKernel {
             const float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
             float l2 = l2o - u2c * sh.rAinv[r0 + 2];
             const float lim = mu * ln, nt = sqrtf(l1 * l1 + l2 * l2);
-            if (nt > lim) { float sc = nt > 0.0f ? lim / nt : 0.0f; l1 *= sc; l2 *= sc; }
+            if (nt > lim) { float sc = nt > 0.0f ? lim * pf_rcp(nt) : 0.0f; l1 *= sc; l2 *= sc; }
             const float d1 = l1 - l1o, d2 = l2 - l2o;
             v += wc[ci][0] * d0 + wc[ci][1] * d1 + wc[ci][2] * d2;
             lc[ci][0] = ln; lc[ci][1] = l1; lc[ci][2] = l2;
@@ -984,7 +995,7 @@ struct PfKernel {
           float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
           float l2 = l2o - u2c * sh.rAinv[r0 + 2];
           float lim = mu * ln, nt = sqrtf(l1 * l1 + l2 * l2);
-          if (nt > lim) { float sc = nt > 0.0f ? lim / nt : 0.0f; l1 *= sc; l2 *= sc; }
+          if (nt > lim) { float sc = nt > 0.0f ? lim * pf_rcp(nt) : 0.0f; l1 *= sc; l2 *= sc; }
           float d1 = l1 - l1o, d2 = l2 - l2o;
 #pragma unroll
           for (int t = 0; t < NV; ++t) v[t] += sh.W[r0][t] * d0 + sh.W[r0 + 1][t] * d1 + sh.W[r0 + 2][t] * d2;
@@ -1039,7 +1050,7 @@ struct PfKernel {
       float ny = qy + (-hx * qz + hy * qw + hz * qx);
       float nz = qz + (hx * qy - hy * qx + hz * qw);
       float nw = qw + (-hx * qx - hy * qy - hz * qz);
-      float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+      float inv = pf_rcp(sqrtf(nx * nx + ny * ny + nz * nz + nw * nw));
       float p0 = S[LC::root] + dt * sh.vel[0], p1 = S[LC::root + 1] + dt * sh.vel[1], p2 = S[LC::root + 2] + dt * sh.vel[2];
       float v6[6];
       for (int t = 0; t < 6; ++t) v6[t] = sh.vel[t];
@@ -1076,7 +1087,7 @@ struct PfKernel {
     float a = 0.0f;
 #pragma unroll
     for (int t = 0; t < NV; ++t) { a += sh.J[rr][t] * w[t]; sh.W[rr][t] = w[t]; }
-    sh.rAinv[rr] = 1.0f / fmaxf(a, 1e-9f);
+    sh.rAinv[rr] = pf_rcp(fmaxf(a, 1e-9f));
   }
   PF_DEV void solve_rows(Shared& sh, int nrows, bool with_free, const float (&Lr)[NLT], const float (&dv)[NDV]) {
     PF_LANES(x, nrows + (with_free ? 1 : 0)) { solve_one(sh, x < nrows ? x : RFREE, Lr, dv); }
