@@ -30,6 +30,17 @@ PF_DEV float pf_rcp(float x) {
   return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 #endif
 }
+// sqrt(x) for the same places (x >= 0, not denormal there): v_sqrt_f32 + one Newton step instead of the scaled IEEE sequence
+PF_DEV float pf_sqrt(float x) {
+#if defined(PF_HOST_EMU)
+  return sqrtf(x);
+#else
+  const float s = __builtin_amdgcn_sqrtf(x);
+  // s + (x - s^2) / (2 s), the residual in one fma; x == 0 gives s == 0 and rcp(0) * 0 -> NaN, so guard it
+  const float h = 0.5f * __builtin_amdgcn_rcpf(s);
+  return s > 0.0f ? __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s) : s;
+#endif
+}
 PF_DEV void pf_cross(const float* a, const float* b, float* o) {
   float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   o[0] = x; o[1] = y; o[2] = z;
@@ -304,9 +315,10 @@ struct PfKernel {
       E01 = (H01 - lo > thr) ? lo : H01; E11 = (H11 - lo > thr) ? lo : H11;
     }
     *h = (1.0f - tx) * ((1.0f - ty) * E00 + ty * E01) + tx * ((1.0f - ty) * E10 + ty * E11);
-    float dhdx = ((1.0f - ty) * (E10 - E00) + ty * (E11 - E01)) / hsc;
-    float dhdy = ((1.0f - tx) * (E01 - E00) + tx * (E11 - E10)) / hsc;
-    float inv = pf_rcp(sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f));
+    const float ihs = pf_rcp(hsc);
+    float dhdx = ((1.0f - ty) * (E10 - E00) + ty * (E11 - E01)) * ihs;
+    float dhdy = ((1.0f - tx) * (E01 - E00) + tx * (E11 - E10)) * ihs;
+    float inv = pf_rcp(pf_sqrt(dhdx * dhdx + dhdy * dhdy + 1.0f));
     n[0] = -dhdx * inv; n[1] = -dhdy * inv; n[2] = inv;
     if (steep) {
       // 0: x-far (normal -x), 1: x-near (+x), 2: y-far (-y), 3: y-near (+y)
@@ -317,7 +329,7 @@ struct PfKernel {
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         const float dz = fmaxf(wz - top[f], 0.0f);
-        const float len = sqrtf(gap[f] * gap[f] + dz * dz);
+        const float len = pf_sqrt(gap[f] * gap[f] + dz * dz);
         const float dist = len - rad;
         const bool take = (top[f] - bot[f] > thr) && dist < best;
         const float il = pf_rcp(fmaxf(len, 1e-9f));
@@ -628,7 +640,7 @@ struct PfKernel {
       sh.bias[a] = bv; sh.vold[a] = vo;
       float rhs = -bv + (a >= 6 ? S[LC::torques + a - 6] : 0.0f);
       if (B.d_joint_friction && a >= 6)     // regularised Coulomb joint friction (update_frictions, :103-108)
-        rhs -= B.d_joint_friction[(size_t)env * ND + a - 6] * pf_clip(vo / c.joint_friction_vel, -1.0f, 1.0f);
+        rhs -= B.d_joint_friction[(size_t)env * ND + a - 6] * pf_clip(vo * pf_rcp(c.joint_friction_vel), -1.0f, 1.0f);
       sh.J[RFREE][a] = rhs; sh.W[RFREE][a] = rhs;
     }
     PF_SYNC();
@@ -645,7 +657,7 @@ struct PfKernel {
         float d = Lr[lt(j, j)];
 #pragma unroll
         for (int t = 0; t < j; ++t) d -= Lr[lt(j, t)] * Lr[lt(j, t)];
-        d = sqrtf(fmaxf(d, 1e-12f));
+        d = pf_sqrt(fmaxf(d, 1e-12f));
         const float di = pf_rcp(d);
         dv[j] = di;
 #pragma unroll
@@ -670,7 +682,7 @@ struct PfKernel {
         float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[j]), j));
 #pragma unroll
         for (int t = 0; t < j; ++t) d -= pj[t] * pj[t];
-        d = sqrtf(fmaxf(d, 1e-12f));
+        d = pf_sqrt(fmaxf(d, 1e-12f));
         const float di = pf_rcp(d);
         float sacc = r[j];
 #pragma unroll
@@ -689,7 +701,7 @@ struct PfKernel {
       for (int j = 0; j < NV; ++j) {
         float d = sh.M[j][j];
         for (int t = 0; t < j; ++t) d -= sh.M[j][t] * sh.M[j][t];
-        d = sqrtf(fmaxf(d, 1e-12f));
+        d = pf_sqrt(fmaxf(d, 1e-12f));
         float di = pf_rcp(d);
         PF_LANES(ii, NV - j - 1) {
           int i = j + 1 + ii;
@@ -728,7 +740,7 @@ struct PfKernel {
         const int a0 = m.cap_s0[ca], b0 = m.cap_s0[cb];
         float v[3], c2[3];
         segment_segment(sh.sphc[a0], sh.sphc[m.cap_s1[ca]], sh.sphc[b0], sh.sphc[m.cap_s1[cb]], v, c2);
-        const float len = sqrtf(pf_dot3(v, v)), rb = m.sph_radius[b0];
+        const float len = pf_sqrt(pf_dot3(v, v)), rb = m.sph_radius[b0];
         const float dist = len - m.sph_radius[a0] - rb;
         const bool ok = len > 1e-9f;
         const float il = pf_rcp(fmaxf(len, 1e-9f));
@@ -798,7 +810,7 @@ struct PfKernel {
       }
       float ref[3] = {fabsf(n[0]) < 0.9f ? 1.0f : 0.0f, fabsf(n[0]) < 0.9f ? 0.0f : 1.0f, 0.0f};
       float t1[3]; pf_cross(n, ref, t1);
-      float il = pf_rcp(sqrtf(pf_dot3(t1, t1)));
+      float il = pf_rcp(pf_sqrt(pf_dot3(t1, t1)));
       for (int t = 0; t < 3; ++t) t1[t] *= il;
       float t2[3]; pf_cross(n, t1, t2);
       float dd[3];
@@ -829,7 +841,8 @@ struct PfKernel {
       for (int a = 0; a < NV; ++a) { sh.J[rr][a] = row[a]; sh.W[rr][a] = row[a]; un0 += row[a] * sh.vold[a]; }
       float bn = 0.0f;
       if (d == 0) {
-        bn = dist >= 0.0f ? -dist / dt : fminf(0.2f * (-dist) / dt, c.max_depenetration_vel);
+        const float idt = pf_rcp(dt);
+        bn = dist >= 0.0f ? -dist * idt : fminf(0.2f * (-dist) * idt, c.max_depenetration_vel);
         if (un0 < -c.bounce_threshold) bn = fmaxf(bn, -rest * un0);
       }
       sh.rb[rr] = bn; sh.lam[rr] = 0.0f;
@@ -868,7 +881,8 @@ struct PfKernel {
       for (int a = 0; a < NV; ++a) { float v = (a == 6 + k) ? (float)side : 0.0f; sh.J[rr][a] = v; sh.W[rr][a] = v; }
       float q = S[LC::dof_pos + k];
       float viol = side > 0 ? m.q_lo[k] - q : q - m.q_hi[k];
-      sh.rb[rr] = viol > 0.0f ? fminf(0.2f * viol / dt, 10.0f * c.max_depenetration_vel) : viol / dt;
+      const float idt = pf_rcp(dt);
+      sh.rb[rr] = viol > 0.0f ? fminf(0.2f * viol * idt, 10.0f * c.max_depenetration_vel) : viol * idt;
       sh.lam[rr] = 0.0f;
     }
     PF_SYNC();
@@ -934,7 +948,7 @@ struct PfKernel {
             const float d1p = l1 - l1o;
             const float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
             float l2 = l2o - u2c * sh.rAinv[r0 + 2];
-            const float lim = mu * ln, nt = sqrtf(l1 * l1 + l2 * l2);
+            const float lim = mu * ln, nt = pf_sqrt(l1 * l1 + l2 * l2);
             if (nt > lim) { float sc = nt > 0.0f ? lim * pf_rcp(nt) : 0.0f; l1 *= sc; l2 *= sc; }
             const float d1 = l1 - l1o, d2 = l2 - l2o;
             v += wc[ci][0] * d0 + wc[ci][1] * d1 + wc[ci][2] * d2;
@@ -994,7 +1008,7 @@ struct PfKernel {
           float d1p = l1 - l1o;
           float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
           float l2 = l2o - u2c * sh.rAinv[r0 + 2];
-          float lim = mu * ln, nt = sqrtf(l1 * l1 + l2 * l2);
+          float lim = mu * ln, nt = pf_sqrt(l1 * l1 + l2 * l2);
           if (nt > lim) { float sc = nt > 0.0f ? lim * pf_rcp(nt) : 0.0f; l1 *= sc; l2 *= sc; }
           float d1 = l1 - l1o, d2 = l2 - l2o;
 #pragma unroll
@@ -1036,7 +1050,7 @@ struct PfKernel {
         const float sg = sh.cbody[ci] == i ? 1.0f : ((SELF && sh.cbody_b[ci] == i) ? -1.0f : 0.0f);   // a self-contact pushes the two links apart
         if (sg == 0.0f) continue;
         for (int d = 0; d < 3; ++d) {
-          float l = sg * sh.lam[3 * ci + d] / dt;
+          float l = sg * sh.lam[3 * ci + d] * pf_rcp(dt);
           Fx += l * sh.cdir[ci][3 * d]; Fy += l * sh.cdir[ci][3 * d + 1]; Fz += l * sh.cdir[ci][3 * d + 2];
         }
       }
@@ -1050,7 +1064,7 @@ struct PfKernel {
       float ny = qy + (-hx * qz + hy * qw + hz * qx);
       float nz = qz + (hx * qy - hy * qx + hz * qw);
       float nw = qw + (-hx * qx - hy * qy - hz * qz);
-      float inv = pf_rcp(sqrtf(nx * nx + ny * ny + nz * nz + nw * nw));
+      float inv = pf_rcp(pf_sqrt(nx * nx + ny * ny + nz * nz + nw * nw));
       float p0 = S[LC::root] + dt * sh.vel[0], p1 = S[LC::root + 1] + dt * sh.vel[1], p2 = S[LC::root + 2] + dt * sh.vel[2];
       float v6[6];
       for (int t = 0; t < 6; ++t) v6[t] = sh.vel[t];
