@@ -30,6 +30,33 @@ PF_DEV float pf_rcp(float x) {
   return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 #endif
 }
+// sin and cos of a joint angle (|x| well inside [-pi, pi]: joint limits): Cody-Waite reduction to [-pi/4, pi/4] and the Cephes
+// single-precision minimax polynomials, both values from one reduction -- within 1-2 ulp of sinf / cosf, without the library
+// routines' large-argument machinery (three joints per chain, five kinematics passes per step).  The host build calls libm.
+PF_DEV void pf_sincos(float x, float* sn, float* cs) {
+#if defined(PF_HOST_EMU)
+  *sn = sinf(x); *cs = cosf(x);
+#else
+  const float ax = fabsf(x);
+  int j = (int)(ax * 1.27323954473516f);          // 4 / pi
+  j = (j + 1) & ~1;                                // nearest even multiple of pi / 4 at or above
+  const float y = (float)j;
+  float z = __builtin_fmaf(y, -0.78515625f, ax);
+  z = __builtin_fmaf(y, -2.4187564849853515625e-4f, z);
+  z = __builtin_fmaf(y, -3.77489497744594108e-8f, z);
+  const float zz = z * z;
+  float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, zz, 8.3321608736e-3f), zz, -1.6666654611e-1f);
+  ps = __builtin_fmaf(ps * zz, z, z);
+  float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, zz, -1.388731625493765e-3f), zz, 4.166664568298827e-2f);
+  pc = __builtin_fmaf(pc * zz, zz, __builtin_fmaf(-0.5f, zz, 1.0f));
+  const int q = (j >> 1) & 3;                      // quadrant
+  float s_ = (q & 1) ? pc : ps, c_ = (q & 1) ? ps : pc;
+  if (q == 1 || q == 2) c_ = -c_;
+  if (q >= 2) s_ = -s_;
+  *sn = x < 0.0f ? -s_ : s_;
+  *cs = c_;
+#endif
+}
 // sqrt(x) for the same places (x >= 0, not denormal there): v_sqrt_f32 + one Newton step instead of the scaled IEEE sequence
 PF_DEV float pf_sqrt(float x) {
 #if defined(PF_HOST_EMU)
@@ -494,7 +521,8 @@ struct PfKernel {
           float a[3] = {m.joint_axis[i][0], m.joint_axis[i][1], m.joint_axis[i][2]};
           float aw[3]; pf_mat_vec(Rj, a, aw);
           float th = S[LC::dof_pos + k];
-          float cs = cosf(th), sn = sinf(th), t1 = 1.0f - cs;
+          float cs, sn; pf_sincos(th, &sn, &cs);
+          const float t1 = 1.0f - cs;
           float Ra[9] = {t1 * a[0] * a[0] + cs, t1 * a[0] * a[1] - sn * a[2], t1 * a[0] * a[2] + sn * a[1],
                          t1 * a[0] * a[1] + sn * a[2], t1 * a[1] * a[1] + cs, t1 * a[1] * a[2] - sn * a[0],
                          t1 * a[0] * a[2] - sn * a[1], t1 * a[1] * a[2] + sn * a[0], t1 * a[2] * a[2] + cs};
