@@ -405,7 +405,23 @@ struct PfKernel {
   // ------------------------------------------------------------------ actuator network (anymal.py:71-78)
   // per joint: x = [a*scale + q0 - q, qd] * in_scale -> LSTM(2->8) x 2 layers (state h,c persists, zeroed on reset) ->
   // Linear(8->1) * out_scale.  No torque clip on this branch.  Lanes: (joint, gate row) pairs, then (joint, unit) pairs.
-  PF_DEV float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+  // LSTM gate activations: v_exp_f32-based forms (absolute error ~1e-7) instead of the library expf / tanhf and an IEEE division --
+  // 5 per unit, 96 units per layer, every substep.  The host build keeps libm.
+  PF_DEV float sigm(float x) {
+#if defined(PF_HOST_EMU)
+    return 1.0f / (1.0f + expf(-x));
+#else
+    return pf_rcp(1.0f + __expf(-x));
+#endif
+  }
+  PF_DEV float tanh_(float x) {
+#if defined(PF_HOST_EMU)
+    return tanhf(x);
+#else
+    const float xc = pf_clip(x, -15.0f, 15.0f);              // exp(2 x) stays finite; tanh is +-1 to float precision beyond
+    return 1.0f - 2.0f * pf_rcp(__expf(2.0f * xc) + 1.0f);
+#endif
+  }
   PF_DEV void actuator_torques(Shared& sh, const float* P, const PfConfig& c) {
     float* S = sh.rec;
     for (int layer = 0; layer < 2; ++layer) {
@@ -429,10 +445,10 @@ struct PfKernel {
         int j = e >> 3, u = e & 7;
         const float* G = sh.gates + j * 32;
         float* st = S + LC::lstm_state + j * 32 + layer * 16;
-        float ig = sigm(G[u]), fg = sigm(G[8 + u]), gg = tanhf(G[16 + u]), og = sigm(G[24 + u]);
+        float ig = sigm(G[u]), fg = sigm(G[8 + u]), gg = tanh_(G[16 + u]), og = sigm(G[24 + u]);
         float cn = fg * st[8 + u] + ig * gg;
         st[8 + u] = cn;
-        st[u] = og * tanhf(cn);
+        st[u] = og * tanh_(cn);
       }
       PF_SYNC();
     }
