@@ -139,6 +139,21 @@ PF_DEV float pf_wrap_to_pi(float a) {
 }
 
 // Philox4x32-10 (Salmon et al. 2011); counter = (global env, step, stream, slot/4), key = seed
+// the whole block of four slots 4 b .. 4 b + 3 (pf_philox_slot keeps one of them): a block costs ten rounds of two 32 x 32 -> 64
+// multiplies, so long runs of consecutive slots are drawn block-wise, one block per lane (PfKernel::noise_prepare)
+PF_DEV void pf_philox_block(uint32_t k0, uint32_t k1, uint32_t env, uint32_t step, uint32_t stream, uint32_t block, float* out4) {
+  uint32_t c0 = env, c1 = step, c2 = stream, c3 = block;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out4[0] = (float)(c0 >> 8) * (1.0f / 16777216.0f); out4[1] = (float)(c1 >> 8) * (1.0f / 16777216.0f);
+  out4[2] = (float)(c2 >> 8) * (1.0f / 16777216.0f); out4[3] = (float)(c3 >> 8) * (1.0f / 16777216.0f);
+}
 PF_DEV float pf_philox_slot(uint32_t k0, uint32_t k1, uint32_t env, uint32_t step, uint32_t stream, uint32_t slot) {
   uint32_t c0 = env, c1 = step, c2 = stream, c3 = slot >> 2;
 #pragma unroll
@@ -295,6 +310,9 @@ struct PfKernel {
   // the height scan (post-physics only) reuses the constraint-row storage (physics only)
   static_assert(NROWS * NVP >= PF_MAX_HPTS, "height scan does not fit the aliased row storage");
   PF_DEV float* heights_of(Shared& sh) { return &sh.J[0][0]; }
+  // ... and the block-wise uniform draws of the observation noise reuse the other row array
+  static_assert(NROWS * NVP >= 4 * (PF_MAX_OBS / 4 + 2), "noise scratch does not fit the aliased row storage");
+  PF_DEV float* noise_of(Shared& sh) { return &sh.W[0][0]; }
 
   // ------------------------------------------------------------------ terrain
   // point_foot.py:1100-1112 for one point; exact float32 op order of the reference, no FMA contraction
@@ -400,6 +418,21 @@ struct PfKernel {
   PF_DEV float rnd(const PfConfig& c, const PfLayout& L, const PfInject& inj, int env, long long step, int slot) {
     if (inj.d_rand) return inj.d_rand[(size_t)env * L.rand_floats + slot];
     return pf_philox_slot(c.seed_lo, c.seed_hi, (uint32_t)(c.env_index_base + env), (uint32_t)step, 0u, (uint32_t)slot);
+  }
+
+  // Uniform draws for the consecutive slots [first, first + count): one Philox block (four slots) per lane into LDS, instead of
+  // one block per lane PER SLOT.  noise_at(slot) then returns exactly what rnd(slot) would.  (Tests that inject the draws
+  // bypass it.)
+  PF_DEV void noise_prepare(Shared& sh, const PfConfig& c, const PfInject& inj, int env, long long step, int first, int count) {
+    if (inj.d_rand) return;
+    const int b0 = first >> 2, nb = ((first + count - 1) >> 2) - b0 + 1;
+    float* sc = noise_of(sh);
+    PF_LANES(b, nb) pf_philox_block(c.seed_lo, c.seed_hi, (uint32_t)(c.env_index_base + env), (uint32_t)step, 0u, (uint32_t)(b0 + b), sc + 4 * b);
+    PF_SYNC();
+  }
+  PF_DEV float noise_at(Shared& sh, const PfLayout& L, const PfInject& inj, int env, int first, int slot) {
+    if (inj.d_rand) return inj.d_rand[(size_t)env * L.rand_floats + slot];
+    return noise_of(sh)[slot - 4 * (first >> 2)];
   }
 
   // ------------------------------------------------------------------ actuator network (anymal.py:71-78)
@@ -1165,6 +1198,7 @@ struct PfKernel {
     if constexpr (LR) {
       // obs = [lin_vel*s (3), ang_vel*s (3), gravity (3), cmd[:3]*scale (3), q-q0 (ND), qd*s (ND), actions (ND), heights (H)]
       const int nprop = 12 + 3 * ND;
+      if (c.add_noise) noise_prepare(sh, c, inj, env, step, L.r_obs, no);
       PF_LANES(i, no) {
         float v;
         if (i < 3) v = S[LC::base_lin_vel + i] * c.obs_scale_lin_vel;
@@ -1175,7 +1209,7 @@ struct PfKernel {
         else if (i < 12 + 2 * ND) v = S[LC::dof_vel + i - 12 - ND] * c.obs_scale_dof_vel;
         else if (i < nprop) v = S[LC::actions + i - 12 - 2 * ND];
         else v = pf_clip((S[LC::root + 2] - 0.5f) - hts[i - nprop], -1.0f, 1.0f) * c.obs_scale_height;
-        if (c.add_noise) v += (2.0f * rnd(c, L, inj, env, step, L.r_obs + i) - 1.0f) * c.obs_noise_vec[i];
+        if (c.add_noise) v += (2.0f * noise_at(sh, L, inj, env, L.r_obs, L.r_obs + i) - 1.0f) * c.obs_noise_vec[i];
         B.d_obs[(size_t)env * no + i] = pf_clip(v, -c.clip_obs, c.clip_obs);
       }
       return;
@@ -1200,9 +1234,10 @@ struct PfKernel {
       if (B.d_priv) B.d_priv[(size_t)env * np_ + i] = v;
     }
     if (B.d_priv && c.measure_heights && np_ > no) {
+      if (c.add_noise) noise_prepare(sh, c, inj, env, step, L.r_priv, c.num_height_points);
       PF_LANES(j, c.num_height_points) {    // :367-373
         float h = pf_clip((S[LC::root + 2] - 0.5f) - hts[j], -1.0f, 1.0f) * c.obs_scale_height;
-        if (c.add_noise) h += (2.0f * rnd(c, L, inj, env, step, L.r_priv + j) - 1.0f) * c.priv_height_noise;
+        if (c.add_noise) h += (2.0f * noise_at(sh, L, inj, env, L.r_priv, L.r_priv + j) - 1.0f) * c.priv_height_noise;
         B.d_priv[(size_t)env * np_ + no + j] = pf_clip(h, -c.clip_obs, c.clip_obs);
       }
     }
