@@ -81,9 +81,26 @@ __device__ __forceinline__ void g3_writeout(const GemmArgs& g, float* C, f32x16 
   if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) cvec = cvec && ((((size_t)g.bias) & 15) == 0);
   if (EPI == GEMM_EPI_MUL_DELU) cvec = cvec && ((g.ldh & 3) == 0) && ((((size_t)g.H) & 15) == 0);
   if (cvec) {
-    // every wave transposes its own 32-row strips through a private LDS region and stores whole rows as dwordx4
+    // every wave transposes its own 32-row strips through a private LDS region and stores whole rows as dwordx4.
+    // All global LOADS of the epilogue (bias, the ELU' operand of every strip) are issued before the first STORE: vmcnt retires
+    // in order, so a load issued behind a store is not usable until that store has been acknowledged by memory, and a
+    // "load h, multiply, store" loop pays a store round trip per pass (profiles/r3_gemm_dma_ablation.txt).
     constexpr int WN = BN / 2, CS = WN + 4;                         // strip row stride (floats): 16-byte aligned rows
+    constexpr int Q = WN / 4, P = Q / 2, RP = 64 / Q;               // float4 per strip row; passes per strip; rows per pass
     float* Cs = reinterpret_cast<float*>(smem) + wave * (32 * CS);
+    const int c4 = lane % Q, r0 = lane / Q, col = n0 + wc * WN + 4 * c4;
+    const bool cok = col < g.N;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), hv[TM][P];
+    if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) { if (cok) b4 = *reinterpret_cast<const float4*>(g.bias + col); }
+    if (EPI == GEMM_EPI_MUL_DELU) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int row = m0 + wr * (BM / 2) + 32 * i + r0 + RP * p;
+          hv[i][p] = (row < g.M && cok) ? *reinterpret_cast<const float4*>(g.H + (size_t)row * g.ldh + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -91,25 +108,18 @@ __device__ __forceinline__ void g3_writeout(const GemmArgs& g, float* C, f32x16 
 #pragma unroll
         for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * CS + 32 * j + (lane & 31)] = acc[i][j][r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      constexpr int Q = WN / 4;                                     // float4 per strip row
 #pragma unroll
-      for (int e = lane; e < 32 * Q; e += 64) {
-        const int rl = e / Q, c4 = e % Q;
-        const int row = m0 + wr * (BM / 2) + 32 * i + rl, col = n0 + wc * WN + 4 * c4;
-        if (row < g.M && col < g.N) {
-          float4 v = *reinterpret_cast<const float4*>(&Cs[rl * CS + 4 * c4]);
-          if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) {
-            const float4 b4 = *reinterpret_cast<const float4*>(g.bias + col);
-            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-          }
-          if (EPI == GEMM_EPI_BIAS_ELU) { v.x = pf_elu(v.x); v.y = pf_elu(v.y); v.z = pf_elu(v.z); v.w = pf_elu(v.w); }
-          if (EPI == GEMM_EPI_MUL_DELU) {
-            const float4 h = *reinterpret_cast<const float4*>(g.H + (size_t)row * g.ldh + col);
-            v.x *= (h.x > 0.0f ? 1.0f : h.x + 1.0f); v.y *= (h.y > 0.0f ? 1.0f : h.y + 1.0f);
-            v.z *= (h.z > 0.0f ? 1.0f : h.z + 1.0f); v.w *= (h.w > 0.0f ? 1.0f : h.w + 1.0f);
-          }
-          *reinterpret_cast<float4*>(C + (size_t)row * g.ldc + col) = v;
+      for (int p = 0; p < P; ++p) {
+        const int rl = r0 + RP * p, row = m0 + wr * (BM / 2) + 32 * i + rl;
+        float4 v = *reinterpret_cast<const float4*>(&Cs[rl * CS + 4 * c4]);
+        if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+        if (EPI == GEMM_EPI_BIAS_ELU) { v.x = pf_elu(v.x); v.y = pf_elu(v.y); v.z = pf_elu(v.z); v.w = pf_elu(v.w); }
+        if (EPI == GEMM_EPI_MUL_DELU) {
+          const float4 h = hv[i][p];
+          v.x *= (h.x > 0.0f ? 1.0f : h.x + 1.0f); v.y *= (h.y > 0.0f ? 1.0f : h.y + 1.0f);
+          v.z *= (h.z > 0.0f ? 1.0f : h.z + 1.0f); v.w *= (h.w > 0.0f ? 1.0f : h.w + 1.0f);
         }
+        if (row < g.M && cok) *reinterpret_cast<float4*>(C + (size_t)row * g.ldc + col) = v;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }

@@ -1,0 +1,272 @@
+// pf_gemm3f.h — the "bf16x6" dense layer (pf_gemm3.h) with LDS-DMA staging: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue) for the
+// two k-contiguous arrangements of an nn.Linear layer (forward x W^T + b, ELU; data gradient g W * ELU'(h) with the
+// pre-transposed weight planes), gfx950.
+//
+// What changed against pf_gemm3_body (profiles/r2_gemm3_ablation.txt: loads + split + ds_write + barriers cost as much as
+// the MFMAs and did not overlap them):
+//  * nothing is staged through registers.  The fp32 activation tile (128 rows x 32 k) and the three bf16 weight planes
+//    (BN rows x 32 k each) go global -> LDS by `buffer_load_dwordx4 ... lds` (1 KB per wave instruction, out-of-range -> 0),
+//    two LDS stages, so the DMA of k-slice t + 1 runs under the MFMAs of slice t with ONE barrier per slice;
+//  * the workgroup's four wavefronts are stacked 4 x 1: a wave owns 32 rows x all BN columns.  The exact three-way split of
+//    the activations (a = a1 + a2 + a3, bf16 each) is done on the 8 values a lane reads for its A fragment -- every
+//    activation element is split exactly once per block, by the one wave that owns its row, 44 VALU instructions per
+//    6 * BN/32 MFMAs, issued in the MFMA shadow -- and there is no ds_write in the loop at all;
+//  * LDS images are lane-linear (an LDS-DMA writes base + 16 * lane): the bank swizzles sit on the per-lane SOURCE address
+//    and on the fragment read (cdna_hip_programming.md 5.4 rule 21).  A rows are 128 B: chunk c of row r lives at position
+//    c ^ ((r >> 1) & 7), so the 16 lanes of a ds_read_b128 phase (16 different rows, same chunk) cover all 64 banks;
+//    B rows are 64 B with pf_gemm3.h's g3_soff swizzle.
+// HBM formats and the numerics are unchanged (same products, same accumulation order within a k-step).
+#pragma once
+#include "pf_gemm3.h"
+#include <type_traits>
+
+// An LDS-DMA issued through the builtin is counted by hipcc, which then drains it (s_waitcnt vmcnt(0)) ahead of the first
+// ds_read that follows -- the MFMAs of a slice would wait for the NEXT slice's DMA.  The loads therefore go out as inline
+// asm (hipcc does not count them; the loop waits for them itself, once per slice), with the buffer descriptor built by hand.
+// M0 (the LDS destination base of the DMA) is compiler-reserved: saved and restored inside the statement.
+typedef unsigned g3f_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ g3f_u4 g3f_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  g3f_u4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};      // raw buffer (stride 0), out-of-range reads return 0
+  return r;
+}
+__device__ __forceinline__ void g3f_dma16(const g3f_u4& rsrc, unsigned voff, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(rsrc) : "memory");
+}
+// Diagnostic builds only (tools/gemm_dma_ablate.hip): -DG3F_ABLATE=mask removes one ingredient at a time (results are wrong by
+// construction).  1 MFMAs, 2 activation split, 4 in-loop DMA, 8 B fragment reads, 16 A fragment reads, 32 write-out, 64 the write-out's global
+// stores only, 128 the write-out's LDS transpose only.
+#ifndef G3F_ABLATE
+#define G3F_ABLATE 0
+#endif
+constexpr int G3F_BM = 128, G3F_BK = 32, G3F_A_BYTES = G3F_BM * G3F_BK * 4;
+template <int BN> constexpr int g3f_stage_bytes() { return G3F_A_BYTES + 3 * BN * G3F_BK * 2; }
+template <int BN> constexpr int g3f_lds_bytes() {
+  // two operand stages; the write-out strips (4 waves x 32 rows x (BN + 4) floats) reuse the same bytes
+  constexpr int op = 2 * g3f_stage_bytes<BN>(), st = 4 * 32 * (BN + 4) * 4;
+  return op > st ? op : st;
+}
+
+template <int BN, int EPI>
+__device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid, const int nblk, unsigned char* smem) {
+  constexpr int BM = G3F_BM, BK = G3F_BK, TN = BN / 32;
+  constexpr int A_BYTES = G3F_A_BYTES, PLANE_B = BN * BK * 2, STAGE = g3f_stage_bytes<BN>();
+  constexpr int NPB = 3 * BN / 16;            // 1 KB pieces of the B planes per stage (16 rows x 64 B each)
+  static_assert(NPB % 4 == 0, "B pieces are dealt evenly to the four waves");
+  constexpr int BPW = NPB / 4;
+  constexpr unsigned OOB = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (g.N + BN - 1) / BN, tiles_y = (g.M + BM - 1) / BM;
+  const int ntiles = tiles_x * tiles_y;
+  const int per_xcd = (ntiles + 7) >> 3, tmax = per_xcd << 3;
+  const g3f_u4 a_rs = g3f_rsrc(g.A, (unsigned)g.M * (unsigned)g.lda * 4u), b_rs = g3f_rsrc(g.Bp, (unsigned)(3ll * g.bplane * 2ll));
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;      // LDS byte address of the stages
+
+  for (int t = bid; t < tmax; t += nblk) {
+    const int lt = (t & 7) * per_xcd + (t >> 3);      // XCD (t & 7) owns a contiguous range of logical tiles (shared A rows hit one L2)
+    if (lt >= ntiles) continue;
+    const int bx = lt % tiles_x, by = lt / tiles_x;
+    const int m0 = by * BM, n0 = bx * BN;
+    // per-lane source offsets of this wave's DMA pieces (k0 = 0); the A pieces of a wave are its own 32 rows
+    unsigned a_off[4], b_off[BPW];
+    int a_k[4], b_k[BPW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = 32 * wave + 8 * i + (lane >> 3), c = (lane & 7) ^ ((rl >> 1) & 7), row = m0 + rl;
+      a_k[i] = 4 * c;
+      a_off[i] = row < g.M ? ((unsigned)row * (unsigned)g.lda + 4u * c) * 4u : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+      const int q = wave * BPW + i, p = q / (BN / 16), rl = 16 * (q % (BN / 16)) + (lane >> 2), c = (lane & 3) ^ ((rl >> 2) & 3), row = n0 + rl;
+      b_k[i] = 8 * c;
+      b_off[i] = row < g.N ? (unsigned)(((long long)p * g.bplane + (long long)row * g.ldbp + 8 * c) * 2ll) : OOB;
+    }
+    // DMA piece i of this wave for the slice at k0 into stage `buf`: i < 4 its A rows, then its share of the B planes
+    constexpr int NP = 4 + BPW;
+    auto piece = [&](int i, int k0, int buf, bool full) {
+      const unsigned st = lds0 + buf * STAGE;
+      if (i < 4) {
+        unsigned off = a_off[i] + 4u * (unsigned)k0;
+        if (!full) off = (k0 + a_k[i] < g.K) ? off : OOB;
+        g3f_dma16(a_rs, off, st + (4 * wave + i) * 1024);
+      } else {
+        unsigned off = b_off[i - 4] + 2u * (unsigned)k0;
+        if (!full) off = (k0 + b_k[i - 4] < g.ldbp) ? off : OOB;
+        g3f_dma16(b_rs, off, st + A_BYTES + (wave * BPW + i - 4) * 1024);
+      }
+    };
+    auto is_full = [&](int k0) { return k0 + BK <= g.K && k0 + BK <= g.ldbp; };      // uniform: only a ragged last slice checks k per lane
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    const int rl = 32 * wave + (lane & 31), kh = lane >> 5, aswz = (rl >> 1) & 7;
+    const int nt = (g.K + BK - 1) / BK;
+    // one k-slice of MFMAs out of stage it & 1; with NEXT, the DMA pieces of slice it + 1 go out between the MFMA groups
+    // (a burst of them at the head of the slice keeps every wave of the CU in the load queue while the matrix pipes idle)
+    auto slice = [&](int it, auto next_tag) {
+      constexpr bool NEXT = decltype(next_tag)::value && (G3F_ABLATE & 4) == 0;
+      const int k0n = (it + 1) * BK, bufn = (it + 1) & 1;
+      const bool fulln = is_full(k0n);
+      const unsigned char* st = smem + ((G3F_ABLATE & 4) ? 0 : (it & 1)) * STAGE;
+      const uint16_t* Bs = reinterpret_cast<const uint16_t*>(st + A_BYTES);
+      constexpr int G = 2 * TN;      // MFMA groups of a slice
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        const int c0 = 4 * kk + 2 * kh;
+        float4 v0, v1;
+        if constexpr ((G3F_ABLATE & 16) == 0) {
+          v0 = *reinterpret_cast<const float4*>(st + rl * 128 + ((c0 ^ aswz) << 4));
+          v1 = *reinterpret_cast<const float4*>(st + rl * 128 + (((c0 + 1) ^ aswz) << 4));
+        } else { v0 = make_float4(1.0f + lane, 2.0f, 3.0f + kk, 4.0f); v1 = v0; asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v1.x), "+v"(v1.w)); }
+        uint4 q0, q1, q2;
+        if constexpr ((G3F_ABLATE & 2) == 0) g3_split8(v0, v1, q0, q1, q2);
+        else { q0 = __builtin_bit_cast(uint4, v0); q1 = __builtin_bit_cast(uint4, v1); q2 = q0; }
+        const pf_bf16x8 a0 = __builtin_bit_cast(pf_bf16x8, q0), a1 = __builtin_bit_cast(pf_bf16x8, q1), a2 = __builtin_bit_cast(pf_bf16x8, q2);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const uint16_t* bp = Bs + g3_soff(32 * j + (lane & 31), 2 * kk + kh);
+          pf_bf16x8 b0, b1, b2;
+          if constexpr ((G3F_ABLATE & 8) == 0) {
+            b0 = *reinterpret_cast<const pf_bf16x8*>(bp);
+            b1 = *reinterpret_cast<const pf_bf16x8*>(bp + PLANE_B / 2);
+            b2 = *reinterpret_cast<const pf_bf16x8*>(bp + PLANE_B);
+          } else { b0 = a0; b1 = a1; b2 = a2; asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2)); }      // opaque: no CSE across j
+          if constexpr ((G3F_ABLATE & 1) != 0) { G3_KEEP(a0); G3_KEEP(a1); G3_KEEP(a2); G3_KEEP(b0); G3_KEEP(b1); G3_KEEP(b2); }
+          else {
+            // smallest terms first
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+          }
+          if constexpr (NEXT) {
+            constexpr int dummy = 0; (void)dummy;
+            const int grp = kk * TN + j;
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+              if (i * G / NP == grp) piece(i, k0n, bufn, fulln);
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < NP; ++i) piece(i, 0, 0, is_full(0));
+    for (int it = 0; it + 1 < nt; ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of slice `it` have landed
+      __syncthreads();                                      // ... everybody's have; and everybody is done reading the other stage
+      slice(it, std::true_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    slice(nt - 1, std::false_type{});
+    __syncthreads();            // every wave is done with the operand stages: LDS becomes the write-out staging area
+    if constexpr ((G3F_ABLATE & 32) != 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[j]));      // all accumulators stay live (no dead MFMA chains)
+      continue;
+    }
+    // Write-out: a wave transposes its own 32 x BN strip through a private LDS region and stores whole rows as dwordx4.
+    // C/D layout of a 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    // Every global LOAD of the epilogue (bias, the ELU' operand) is issued before the first STORE: vmcnt retires in order, so a
+    // load issued after a store cannot be consumed before that store has been acknowledged by memory -- a loop of
+    // "load h, multiply, store" pays one full store round trip per pass (measured: 22 of this kernel's 47 us).
+    {
+      constexpr int CS = BN + 4, Q = BN / 4, P = Q / 2, RP = 64 / Q;      // float4 per row; passes; rows per pass
+      float* Cs = reinterpret_cast<float*>(smem) + wave * (32 * CS);
+      const int c4 = lane % Q, r0 = lane / Q, col = n0 + 4 * c4;
+      const bool cok = col < g.N;
+      const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (unsigned)g.M * (unsigned)g.ldc * 4u, 0x00020000);
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), hv[P];
+      if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) { if (cok) b4 = *reinterpret_cast<const float4*>(g.bias + col); }
+      if (EPI == GEMM_EPI_MUL_DELU) {
+        const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.H), 0, (unsigned)g.M * (unsigned)g.ldh * 4u, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int row = m0 + 32 * wave + r0 + RP * p;
+          hv[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rs, (int)((row < g.M && cok) ? ((unsigned)row * (unsigned)g.ldh + (unsigned)col) * 4u : OOB), 0, 0));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { if constexpr ((G3F_ABLATE & 128) == 0) Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * CS + 32 * j + (lane & 31)] = acc[j][r]; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int r = r0 + RP * p, row = m0 + 32 * wave + r;
+        float4 v;
+        if constexpr ((G3F_ABLATE & 128) == 0) v = *reinterpret_cast<const float4*>(&Cs[r * CS + 4 * c4]);
+        else v = make_float4(acc[p % TN][0], acc[p % TN][1 + p / TN], acc[p % TN][5 + p / TN], acc[p % TN][10]);
+        if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+        if (EPI == GEMM_EPI_BIAS_ELU) { v.x = pf_elu(v.x); v.y = pf_elu(v.y); v.z = pf_elu(v.z); v.w = pf_elu(v.w); }
+        if (EPI == GEMM_EPI_MUL_DELU) {
+          const float4 h = hv[p];
+          v.x *= (h.x > 0.0f ? 1.0f : h.x + 1.0f); v.y *= (h.y > 0.0f ? 1.0f : h.y + 1.0f);
+          v.z *= (h.z > 0.0f ? 1.0f : h.z + 1.0f); v.w *= (h.w > 0.0f ? 1.0f : h.w + 1.0f);
+        }
+        if constexpr ((G3F_ABLATE & 64) != 0) { G3_KEEP(v.x); G3_KEEP(v.y); G3_KEEP(v.z); G3_KEEP(v.w); continue; }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g3f_u4, v), c_rs, (int)((row < g.M && cok) ? ((unsigned)row * (unsigned)g.ldc + (unsigned)col) * 4u : OOB), 0, 0);
+      }
+    }
+    __syncthreads();            // (a block that walks on to another tile re-fills the stages)
+  }
+}
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void pf_gemm3f_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[g3f_lds_bytes<BN>()];
+  pf_gemm3f_body<BN, EPI>(g, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+// layer i of the actor and of the critic in one launch
+template <int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void pf_gemm3f_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[g3f_lds_bytes<BN>()];
+  if ((int)blockIdx.x < nb0) pf_gemm3f_body<BN, EPI>(g0, (int)blockIdx.x, nb0, smem);
+  else pf_gemm3f_body<BN, EPI>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, smem);
+}
+
+// The DMA path moves whole 16-byte chunks and the write-out whole float4: rows of A, C (and H) 16-byte aligned, K and N
+// multiples of 4, B handed over as planes.  Anything else stays on pf_gemm3_body.
+template <int EPI>
+static inline bool pf_gemm3f_ok(const GemmArgs& g) {
+  auto al = [](const void* p) { return (((size_t)p) & 15) == 0; };
+  bool ok = g.Bp && al(g.Bp) && al(g.A) && al(g.C) && (g.lda & 3) == 0 && (g.ldc & 3) == 0 && (g.K & 3) == 0 && (g.N & 3) == 0 && (g.ldbp & 7) == 0 &&
+            ((g.bplane * 2) & 15) == 0 && (long long)g.M * g.lda * 4ll < (1ll << 31) && (long long)g.M * g.ldc * 4ll < (1ll << 31) && 3ll * g.bplane * 2ll < (1ll << 31);
+  if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) ok = ok && al(g.bias);
+  if (EPI == GEMM_EPI_MUL_DELU) ok = ok && al(g.H) && (g.ldh & 3) == 0 && (long long)g.M * g.ldh * 4ll < (1ll << 31);
+  return ok;
+}
+// BN: 128 columns per block unless that leaves the chip short of blocks (N = 128 at M = 24 576: 192 blocks) or N has a
+// 64-wide remainder
+static inline int pf_gemm3f_pick_bn(int M, int N) {
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  return (N % 128 == 0 && t128 >= 512) || N > 512 ? 128 : 64;
+}
+template <int BN>
+static inline int pf_gemm3f_blocks(const GemmArgs& g) { return (((g.N + BN - 1) / BN) * ((g.M + G3F_BM - 1) / G3F_BM) + 7) / 8 * 8; }
+template <int EPI>
+static inline void pf_gemm3f_launch(const GemmArgs& g, hipStream_t s, int bn = 0) {
+  if (bn == 0) bn = pf_gemm3f_pick_bn(g.M, g.N);
+  if (bn == 128) hipLaunchKernelGGL((pf_gemm3f_kernel<128, EPI>), dim3(pf_gemm3f_blocks<128>(g)), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((pf_gemm3f_kernel<64, EPI>), dim3(pf_gemm3f_blocks<64>(g)), dim3(256), 0, s, g);
+}
+template <int EPI>
+static inline void pf_gemm3f_launch2(const GemmArgs& g0, const GemmArgs& g1, hipStream_t s, int bn = 0) {
+  if (bn == 0) bn = pf_gemm3f_pick_bn(g0.M > g1.M ? g0.M : g1.M, g0.N < g1.N ? g0.N : g1.N);
+  if (bn == 128) {
+    const int nb0 = pf_gemm3f_blocks<128>(g0), nb1 = pf_gemm3f_blocks<128>(g1);
+    hipLaunchKernelGGL((pf_gemm3f_kernel2<128, EPI>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0);
+  } else {
+    const int nb0 = pf_gemm3f_blocks<64>(g0), nb1 = pf_gemm3f_blocks<64>(g1);
+    hipLaunchKernelGGL((pf_gemm3f_kernel2<64, EPI>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0);
+  }
+}

@@ -19,6 +19,7 @@
 #include "../../include/pointfoot_hip_dev.h"
 #include "pf_gemm.h"
 #include "pf_gemm3.h"
+#include "pf_gemm3f.h"
 
 void pf_set_error(const std::string& s);
 
@@ -850,6 +851,7 @@ struct PpoAlg {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool dual = true, fused_heads = true;
   bool paired = true;      // actor + critic layer i in one launch (needs fused_heads and equal depth); else two streams
+  bool dma = true;         // bf16x6 forward / data-gradient GEMMs on the LDS-DMA kernel (pf_gemm3f.h) where shapes allow
   bool split3 = true;      // dense layers on the bf16 matrix pipes by exact three-way operand split (pf_gemm3.h); false: fp32 MFMA
   int max_rows = 0, max_width = 0, splits = 0;
 };
@@ -1006,7 +1008,8 @@ static void mlp_forward(PpoAlg* a, const Net& n, const float* X, int M, const si
       g.A = in; g.B = P + L.w; g.C = out; g.M = M; g.N = L.out; g.K = L.in; g.lda = L.in; g.ldb = L.in; g.ldc = L.out; g.bias = P + L.b;
       use_planes(a, g, &n == &a->actor ? 0 : 1, i, false);
       if (i == 0 && ldx > 0) pad_input(g, ldx);
-      if (a->split3) pf_gemm3_launch<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
+      if (a->split3 && a->dma && pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(g)) pf_gemm3f_launch<GEMM_EPI_BIAS_ELU>(g, s);
+      else if (a->split3) pf_gemm3_launch<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
       else pf_gemm_auto<true, true, GEMM_EPI_BIAS_ELU>(g, 0, s);
     }
     in = out;
@@ -1045,7 +1048,8 @@ static void mlp_backward(PpoAlg* a, const Net& n, const float* X, int M, const s
       g.H = ws + w_h[i - 1]; g.ldh = L.in;
       if (a->split3) {      // B = W^T planes, k (= out) contiguous
         use_planes(a, g, &n == &a->actor ? 0 : 1, i, true);
-        pf_gemm3_launch<true, true, GEMM_EPI_MUL_DELU>(g, 0, s);
+        if (a->dma && pf_gemm3f_ok<GEMM_EPI_MUL_DELU>(g)) pf_gemm3f_launch<GEMM_EPI_MUL_DELU>(g, s);
+        else pf_gemm3_launch<true, true, GEMM_EPI_MUL_DELU>(g, 0, s);
       }
       else pf_gemm_auto<true, false, GEMM_EPI_MUL_DELU>(g, 0, s);
     }
@@ -1096,7 +1100,8 @@ static void mlp_forward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M,
     use_planes(a, ga, 0, i, false); use_planes(a, gc, 1, i, false);
     if (i == 0 && ldxa > 0) pad_input(ga, ldxa);
     if (i == 0 && ldxc > 0) pad_input(gc, ldxc);
-    if (a->split3) pf_gemm3_launch2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);
+    if (a->split3 && a->dma && pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(gc) && pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(ga)) pf_gemm3f_launch2<GEMM_EPI_BIAS_ELU>(gc, ga, s);
+    else if (a->split3) pf_gemm3_launch2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);
     else pf_gemm_auto2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);     // the larger problem (critic) first
     ina = ws + a->w_ha[i]; inc = ws + a->w_hc[i];
   }
@@ -1125,7 +1130,8 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
       }
       if (a->split3) {      // B = W^T planes, k (= out) contiguous
         use_planes(a, g[0], 0, i, true); use_planes(a, g[1], 1, i, true);
-        pf_gemm3_launch2<true, true, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
+        if (a->dma && pf_gemm3f_ok<GEMM_EPI_MUL_DELU>(g[1]) && pf_gemm3f_ok<GEMM_EPI_MUL_DELU>(g[0])) pf_gemm3f_launch2<GEMM_EPI_MUL_DELU>(g[1], g[0], s);
+        else pf_gemm3_launch2<true, true, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
       }
       else pf_gemm_auto2<true, false, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
     }
@@ -1203,6 +1209,24 @@ int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, 
     else pf_gemm_launch<64, 64, AK, BK_, E, CS>(g, S, s);
   };
   using T = std::true_type; using F = std::false_type;
+  if (mode >= 30) {      // bf16x6 with LDS-DMA staging (pf_gemm3f.h); tile: 0 auto, 64 / 128 = columns per block
+    const int Kp = (K + 7) & ~7;
+    SplitJobs js; js.n = 1;
+    js.j[0] = SplitJob{B, reinterpret_cast<unsigned short*>(ws), N, K, mode == 30 ? K : N, Kp, mode == 30 ? 0 : 1, (long long)N * Kp, 0};
+    js.j[0].blocks = (int)(((long long)N * Kp + 255) / 256);
+    hipLaunchKernelGGL(k_split_weights, dim3(js.j[0].blocks), dim3(256), 0, s, js);
+    g.lda = K; g.ldb = K; g.Bp = reinterpret_cast<const unsigned short*>(ws); g.ldbp = Kp; g.bplane = (long long)N * Kp;
+    const int bn = tile > 0 ? tile : 0;
+    if (mode == 30) {
+      if (!pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(g)) { pf_set_error("pf_gemm_test: shape / alignment not eligible for the LDS-DMA kernel"); return 2; }
+      pf_gemm3f_launch<GEMM_EPI_BIAS_ELU>(g, s, bn);
+    } else {
+      if (!pf_gemm3f_ok<GEMM_EPI_MUL_DELU>(g)) { pf_set_error("pf_gemm_test: shape / alignment not eligible for the LDS-DMA kernel"); return 2; }
+      pf_gemm3f_launch<GEMM_EPI_MUL_DELU>(g, s, bn);
+    }
+    PPO_HIP_OK(hipGetLastError());
+    return 0;
+  }
   if (mode >= 20) {      // bf16x6 with B (the weights) pre-split into bf16 planes in `ws`, as the PPO path runs the dense layers
     const int Kp = (K + 7) & ~7;
     SplitJobs js; js.n = 1;
@@ -1283,6 +1307,7 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
     a->split3 = cfg->gemm_mode == 2 || (cfg->gemm_mode == 0 && widest >= 256);
   }
   if (const char* gm = getenv("PF_PPO_GEMM")) a->split3 = atoi(gm) == 2;       // diagnostics: 1 = fp32 MFMA, 2 = bf16x6
+  if (const char* dm = getenv("PF_PPO_DMA")) a->dma = atoi(dm) != 0;           // diagnostics: 0 = register-staged bf16x6 kernels everywhere
   if (const char* fh = getenv("PF_PPO_FUSED_HEADS")) a->fused_heads = atoi(fh) != 0;
   if (const char* pr = getenv("PF_PPO_PAIRED")) a->paired = atoi(pr) != 0;
   a->paired = a->paired && a->fused_heads && a->actor.nl == a->critic.nl;

@@ -1,0 +1,39 @@
+// Diagnostic: what is the LDS-DMA bf16-split GEMM's (pf_gemm3f.h) time made of?  Built once per -DG3F_ABLATE mask by
+// tools/gemm_dma_ablate.sh; results of an ablated build are wrong by construction -- only times are read.
+//   gemm_dma_ablate MODE M N K BN [ZEROS]      MODE 0 FWD (x W^T + b, ELU), 1 BWD_X;  BN 128 / 64 / 0 auto
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../pointfoot_amd/csrc/pf_gemm3f.h"
+#define OK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+int main(int argc, char** argv) {
+  const int mode = atoi(argv[1]), M = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]), bn = atoi(argv[5]);
+  float *A, *Cm, *bias, *H; unsigned short* Bp;
+  const int ldbp = (K + 7) / 8 * 8;
+  OK(hipMalloc(&A, (size_t)M * K * 4)); OK(hipMalloc(&Cm, (size_t)M * N * 4));
+  OK(hipMalloc(&bias, (size_t)N * 4)); OK(hipMalloc(&H, (size_t)M * N * 4)); OK(hipMalloc(&Bp, (size_t)3 * N * ldbp * 2));
+  std::vector<float> h((size_t)M * (K > N ? K : N));
+  const bool zeros = argc > 6 && atoi(argv[6]) != 0;
+  for (auto& v : h) v = zeros ? 0.0f : (float)rand() / RAND_MAX - 0.5f;
+  OK(hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
+  OK(hipMemset(bias, 0, N * 4)); OK(hipMemcpy(H, h.data(), (size_t)M * N * 4, hipMemcpyHostToDevice));
+  OK(hipMemset(Bp, zeros ? 0 : 0x3c, (size_t)3 * N * ldbp * 2));
+  GemmArgs g{};
+  g.A = A; g.C = Cm; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.bias = bias; g.H = H; g.ldh = N;
+  g.Bp = Bp; g.ldbp = ldbp; g.bplane = (long long)N * ldbp;
+  hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
+  auto launch = [&]() {
+    if (mode == 0) pf_gemm3f_launch<GEMM_EPI_BIAS_ELU>(g, 0, bn);
+    else pf_gemm3f_launch<GEMM_EPI_MUL_DELU>(g, 0, bn);
+  };
+  for (int i = 0; i < 5; ++i) launch();
+  OK(hipDeviceSynchronize());
+  const int iters = 50;
+  OK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) launch();
+  OK(hipEventRecord(e1, 0)); OK(hipEventSynchronize(e1));
+  float ms; OK(hipEventElapsedTime(&ms, e0, e1));
+  printf("ablate %2d mode %d M=%d N=%d K=%d bn %d%s: %.1f us\n", G3F_ABLATE, mode, M, N, K, bn, zeros ? " zeros" : "", ms * 1000.0f / iters);
+  return 0;
+}
