@@ -1216,7 +1216,7 @@ int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, 
     js.j[0].blocks = (int)(((long long)N * Kp + 255) / 256);
     hipLaunchKernelGGL(k_split_weights, dim3(js.j[0].blocks), dim3(256), 0, s, js);
     g.lda = K; g.ldb = K; g.Bp = reinterpret_cast<const unsigned short*>(ws); g.ldbp = Kp; g.bplane = (long long)N * Kp;
-    const int bn = tile > 0 ? tile : 0;
+    const int bn = tile >= 0 ? tile : -1;      // variant: 0 (128, 32), 1 (64, 32), 2 (128, 16); -1 auto
     if (mode == 30) {
       if (!pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(g)) { pf_set_error("pf_gemm_test: shape / alignment not eligible for the LDS-DMA kernel"); return 2; }
       pf_gemm3f_launch<GEMM_EPI_BIAS_ELU>(g, s, bn);

@@ -1,6 +1,7 @@
 // Diagnostic: what is the LDS-DMA bf16-split GEMM's (pf_gemm3f.h) time made of?  Built once per -DG3F_ABLATE mask by
 // tools/gemm_dma_ablate.sh; results of an ablated build are wrong by construction -- only times are read.
-//   gemm_dma_ablate MODE M N K BN [ZEROS]      MODE 0 FWD (x W^T + b, ELU), 1 BWD_X;  BN 128 / 64 / 0 auto
+//   gemm_dma_ablate MODE M N K BN [ZEROS] [PAIR]      MODE 0 FWD (x W^T + b, ELU), 1 BWD_X;  BN = kernel variant: 0 (128 columns, BK 32), 1 (64, 32), 2 (128, 16), -1 auto;
+//   PAIR 1: two problems of this shape in one launch (as the PPO update issues the actor's and the critic's layer)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -22,9 +23,13 @@ int main(int argc, char** argv) {
   GemmArgs g{};
   g.A = A; g.C = Cm; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.bias = bias; g.H = H; g.ldh = N;
   g.Bp = Bp; g.ldbp = ldbp; g.bplane = (long long)N * ldbp;
+  const bool pair = argc > 7 && atoi(argv[7]) != 0;
+  GemmArgs g2 = g;
+  if (pair) { float* C2; OK(hipMalloc(&C2, (size_t)M * N * 4)); g2.C = C2; }
   hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if (mode == 0) pf_gemm3f_launch<GEMM_EPI_BIAS_ELU>(g, 0, bn);
+    if (pair) { if (mode == 0) pf_gemm3f_launch2<GEMM_EPI_BIAS_ELU>(g, g2, 0, bn); else pf_gemm3f_launch2<GEMM_EPI_MUL_DELU>(g, g2, 0, bn); }
+    else if (mode == 0) pf_gemm3f_launch<GEMM_EPI_BIAS_ELU>(g, 0, bn);
     else pf_gemm3f_launch<GEMM_EPI_MUL_DELU>(g, 0, bn);
   };
   for (int i = 0; i < 5; ++i) launch();
@@ -34,6 +39,6 @@ int main(int argc, char** argv) {
   for (int i = 0; i < iters; ++i) launch();
   OK(hipEventRecord(e1, 0)); OK(hipEventSynchronize(e1));
   float ms; OK(hipEventElapsedTime(&ms, e0, e1));
-  printf("ablate %2d mode %d M=%d N=%d K=%d bn %d%s: %.1f us\n", G3F_ABLATE, mode, M, N, K, bn, zeros ? " zeros" : "", ms * 1000.0f / iters);
+  printf("ablate %2d mode %d M=%d N=%d K=%d bn %d%s%s: %.1f us\n", G3F_ABLATE, mode, M, N, K, bn, zeros ? " zeros" : "", pair ? " pair" : "", ms * 1000.0f / iters);
   return 0;
 }
