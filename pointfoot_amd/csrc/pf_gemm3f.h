@@ -38,11 +38,13 @@ __device__ __forceinline__ void g3f_dma16(const g3f_u4& rsrc, unsigned voff, uns
 // Diagnostic builds only (tools/gemm_dma_ablate.hip): -DG3F_ABLATE=mask removes one ingredient at a time (results are wrong by
 // construction).  1 MFMAs, 2 activation split, 4 in-loop DMA, 8 B fragment reads, 16 A fragment reads, 32 write-out, 64 the write-out's global
 // stores only, 128 the write-out's LDS transpose only.
-#ifndef G3F_SCHED
-#define G3F_SCHED 0
-#endif
 #ifndef G3F_ABLATE
 #define G3F_ABLATE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define G3F_OPAQUE(...) asm volatile("" : __VA_ARGS__)      // register constraints of the ablation sinks only parse for the device
+#else
+#define G3F_OPAQUE(...)
 #endif
 constexpr int G3F_BM = 128;
 // Stage geometry for a k-slice of BK (32 or 16): A rows are BK fp32 (128 / 64 B), B rows BK bf16 per plane (64 / 32 B).  A 1 KB
@@ -134,7 +136,7 @@ __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid,
         if constexpr ((G3F_ABLATE & 16) == 0) {
           v0 = *reinterpret_cast<const float4*>(st + rl * Ge::A_ROWB + ((c0 ^ aswz) << 4));
           v1 = *reinterpret_cast<const float4*>(st + rl * Ge::A_ROWB + (((c0 + 1) ^ aswz) << 4));
-        } else { v0 = make_float4(1.0f + lane, 2.0f, 3.0f + kk, 4.0f); v1 = v0; asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v1.x), "+v"(v1.w)); }
+        } else { v0 = make_float4(1.0f + lane, 2.0f, 3.0f + kk, 4.0f); v1 = v0; G3F_OPAQUE("+v"(v0.x), "+v"(v0.y), "+v"(v1.x), "+v"(v1.w)); }
         uint4 q0, q1, q2;
         if constexpr ((G3F_ABLATE & 2) == 0) g3_split8(v0, v1, q0, q1, q2);
         else { q0 = __builtin_bit_cast(uint4, v0); q1 = __builtin_bit_cast(uint4, v1); q2 = q0; }
@@ -148,7 +150,7 @@ __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid,
             b0 = *reinterpret_cast<const pf_bf16x8*>(bp);
             b1 = *reinterpret_cast<const pf_bf16x8*>(bp + PLANE_B);
             b2 = *reinterpret_cast<const pf_bf16x8*>(bp + 2 * PLANE_B);
-          } else { b0 = a0; b1 = a1; b2 = a2; asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2)); }      // opaque: no CSE across j
+          } else { b0 = a0; b1 = a1; b2 = a2; G3F_OPAQUE("+v"(b0), "+v"(b1), "+v"(b2)); }      // opaque: no CSE across j
           if constexpr ((G3F_ABLATE & 1) != 0) { G3_KEEP(a0); G3_KEEP(a1); G3_KEEP(a2); G3_KEEP(b0); G3_KEEP(b1); G3_KEEP(b2); }
           else {
             // smallest terms first
@@ -181,7 +183,7 @@ __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid,
     __syncthreads();            // every wave is done with the operand stages: LDS becomes the write-out staging area
     if constexpr ((G3F_ABLATE & 32) != 0) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[j]));      // all accumulators stay live (no dead MFMA chains)
+      for (int j = 0; j < TN; ++j) G3F_OPAQUE(: "v"(acc[j]));      // all accumulators stay live (no dead MFMA chains)
       continue;
     }
     // Write-out: a wave transposes its own 32-row strip, SW columns at a time, through a private LDS region and stores whole
@@ -243,16 +245,14 @@ __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid,
   }
 }
 
-// BK = 16 halves the stages (20 KB at BN = 128): four workgroups per CU instead of two
-template <int BN, int BK> constexpr int g3f_wg_per_cu() { return 2 * G3fGeom<BN, BK>::LDS <= 40960 * 2 && BK == 16 ? 4 : 2; }
 template <int BN, int BK, int EPI>
-__global__ __launch_bounds__(256, (g3f_wg_per_cu<BN, BK>())) void pf_gemm3f_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void pf_gemm3f_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[G3fGeom<BN, BK>::LDS];
   pf_gemm3f_body<BN, BK, EPI>(g, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 // layer i of the actor and of the critic in one launch
 template <int BN, int BK, int EPI>
-__global__ __launch_bounds__(256, (g3f_wg_per_cu<BN, BK>())) void pf_gemm3f_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
+__global__ __launch_bounds__(256, 2) void pf_gemm3f_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[G3fGeom<BN, BK>::LDS];
   if ((int)blockIdx.x < nb0) pf_gemm3f_body<BN, BK, EPI>(g0, (int)blockIdx.x, nb0, smem);
   else pf_gemm3f_body<BN, BK, EPI>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, smem);
@@ -269,245 +269,29 @@ static inline bool pf_gemm3f_ok(const GemmArgs& g) {
   if (EPI == GEMM_EPI_MUL_DELU) ok = ok && al(g.H) && (g.ldh & 3) == 0 && (long long)g.M * g.ldh * 4ll < (1ll << 31);
   return ok;
 }
-template <int EPI> static inline void pf_gemm3g_launch(const GemmArgs& g, hipStream_t s, int variant);
-template <int EPI> static inline void pf_gemm3g_launch2(const GemmArgs& g0, const GemmArgs& g1, hipStream_t s, int variant);
-// Variant = 10 * BN-code + BK-code.  BN: 128 columns per block unless that leaves the chip short of blocks (`tiles128` = the
-// 128 x 128 tiles of everything in the launch) or N has a 64-wide remainder.  variant ids: 0 (128, 32), 1 (64, 32), 2 (128, 16)
-#ifndef G3F_DEFAULT_BK16
-#define G3F_DEFAULT_BK16 0
-#endif
-static inline int pf_gemm3f_pick(int N, long tiles128) {
-  if (!((N % 128 == 0 && tiles128 >= 512) || N > 512)) return 1;
-  return G3F_DEFAULT_BK16 ? 2 : 0;
-}
+// Variant 0: 128 columns per block; 1: 64 columns -- taken when 128 would leave the chip short of blocks (`tiles128` = the
+// 128 x 128 tiles of everything in the launch: the actor's and the critic's layer share one) or N has a 64-wide remainder.
+// (Measured and dropped, profiles/r3_gemm_dma_ablation.txt: BK = 16 stages for four workgroups per CU; 192-row tiles on
+// v_mfma_f32_16x16x32_bf16.)
+static inline int pf_gemm3f_pick(int N, long tiles128) { return ((N % 128 == 0 && tiles128 >= 512) || N > 512) ? 0 : 1; }
 static inline long pf_gemm3f_tiles128(const GemmArgs& g) { return (long)((g.M + 127) / 128) * ((g.N + 127) / 128); }
 template <int BN>
 static inline int pf_gemm3f_blocks(const GemmArgs& g) { return (((g.N + BN - 1) / BN) * ((g.M + G3F_BM - 1) / G3F_BM) + 7) / 8 * 8; }
 template <int EPI>
 static inline void pf_gemm3f_launch(const GemmArgs& g, hipStream_t s, int variant = -1) {
   if (variant < 0) variant = pf_gemm3f_pick(g.N, pf_gemm3f_tiles128(g));
-  if (variant >= 3) { pf_gemm3g_launch<EPI>(g, s, variant); return; }
   if (variant == 0) hipLaunchKernelGGL((pf_gemm3f_kernel<128, 32, EPI>), dim3(pf_gemm3f_blocks<128>(g)), dim3(256), 0, s, g);
-  else if (variant == 2) hipLaunchKernelGGL((pf_gemm3f_kernel<128, 16, EPI>), dim3(pf_gemm3f_blocks<128>(g)), dim3(256), 0, s, g);
   else hipLaunchKernelGGL((pf_gemm3f_kernel<64, 32, EPI>), dim3(pf_gemm3f_blocks<64>(g)), dim3(256), 0, s, g);
 }
 template <int EPI>
 static inline void pf_gemm3f_launch2(const GemmArgs& g0, const GemmArgs& g1, hipStream_t s, int variant = -1) {
   if (variant < 0) variant = pf_gemm3f_pick(g0.N < g1.N ? g0.N : g1.N, pf_gemm3f_tiles128(g0) + pf_gemm3f_tiles128(g1));
-  if (variant >= 3) { pf_gemm3g_launch2<EPI>(g0, g1, s, variant); return; }
   if (variant == 1) {
     const int nb0 = pf_gemm3f_blocks<64>(g0), nb1 = pf_gemm3f_blocks<64>(g1);
     hipLaunchKernelGGL((pf_gemm3f_kernel2<64, 32, EPI>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0);
     return;
   }
   const int nb0 = pf_gemm3f_blocks<128>(g0), nb1 = pf_gemm3f_blocks<128>(g1);
-  if (variant == 0) hipLaunchKernelGGL((pf_gemm3f_kernel2<128, 32, EPI>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0);
-  else hipLaunchKernelGGL((pf_gemm3f_kernel2<128, 16, EPI>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0);
+  hipLaunchKernelGGL((pf_gemm3f_kernel2<128, 32, EPI>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Big-tile variant for the update's shapes (M = 24 576 rows): 192 x BN block tile, 512 threads = 8 wavefronts as 4 (M) x 2 (N),
-// a wave owns 48 rows x BN/2 columns as 3 x (BN/32) tiles of v_mfma_f32_16x16x32_bf16.
-// Why: the 128 x 128 kernel above is bound by what it moves, not by what it multiplies -- its DMA traffic alone (40 KB per
-// 128 x 128 x 32 of products: every row tile re-streams the weight planes) takes as long as its MFMAs, and on this chip the
-// two do not hide behind each other: they add, the clock falling as more bytes move per MFMA
-// (profiles/r3_gemm_dma_ablation.txt).  192 x 256 moves 24 KB per such unit, reads each B fragment once per 3 row tiles, splits
-// an activation element twice per block instead of once per 64-column pass, and 24 576 / 192 = 128 row tiles x 2 networks
-// x (N / BN) is a whole number of tiles per CU (256 or 512) for every layer of the update -- the 128-row tiles left a
-// quarter of the chip idle in their last round.
-// LDS image (two stages of 72 KB at BN = 256): A rows 128 B, chunk c of row r at position c ^ (((r >> 1) + 2) & 7); B rows 64 B per
-// plane, chunk c of row n at position c ^ {0, 3, 2, 1}[(n >> 2) & 3] -- both found by enumerating the four 16-lane phases of a
-// ds_read_b128 for the 16x16x32 fragment pattern (lane l: row l & 15, k-chunk l >> 4): conflict-free.
-typedef float g3g_f4 __attribute__((ext_vector_type(4)));
-constexpr int G3G_BM = 192, G3G_BK = 32;
-template <int BN> struct G3gGeom {
-  static constexpr int A_BYTES = G3G_BM * 128, PLANE_B = BN * 64, STAGE = A_BYTES + 3 * PLANE_B;
-  static constexpr int A_PW = 3, NPB = 3 * BN / 16, B_PW = NPB / 8, NP = A_PW + B_PW;      // DMA pieces per wave and stage
-  static constexpr int WN = BN / 2, CB = WN / 16;                                          // a wave's columns; its 16-column tiles
-  static constexpr int STRIPS = 8 * 16 * (WN + 4) * 4;
-  static constexpr int LDS = 2 * STAGE > STRIPS ? 2 * STAGE : STRIPS;
-  __device__ static __forceinline__ int a_swz(int r) { return ((r >> 1) + 2) & 7; }
-  __device__ static __forceinline__ int b_swz(int n) { return (0x1230 >> (4 * ((n >> 2) & 3))) & 3; }      // {0, 3, 2, 1}
-};
-
-template <int BN, int EPI>
-__device__ __forceinline__ void pf_gemm3g_body(const GemmArgs& g, const int bid, const int nblk, unsigned char* smem) {
-  using Ge = G3gGeom<BN>;
-  constexpr int BM = G3G_BM, BK = G3G_BK, CB = Ge::CB, WN = Ge::WN;
-  constexpr int A_BYTES = Ge::A_BYTES, PLANE_B = Ge::PLANE_B, STAGE = Ge::STAGE, NP = Ge::NP, A_PW = Ge::A_PW, B_PW = Ge::B_PW;
-  constexpr unsigned OOB = 0x80000000u;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
-  const int tiles_x = (g.N + BN - 1) / BN, tiles_y = (g.M + BM - 1) / BM;
-  const int ntiles = tiles_x * tiles_y;
-  const int per_xcd = (ntiles + 7) >> 3, tmax = per_xcd << 3;
-  const g3f_u4 a_rs = g3f_rsrc(g.A, (unsigned)g.M * (unsigned)g.lda * 4u), b_rs = g3f_rsrc(g.Bp, (unsigned)(3ll * g.bplane * 2ll));
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-
-  for (int t = bid; t < tmax; t += nblk) {
-    const int lt = (t & 7) * per_xcd + (t >> 3);
-    if (lt >= ntiles) continue;
-    const int bx = lt % tiles_x, by = lt / tiles_x;
-    const int m0 = by * BM, n0 = bx * BN;
-    unsigned a_off[A_PW], b_off[B_PW];
-    int a_k[A_PW], b_k[B_PW];
-#pragma unroll
-    for (int i = 0; i < A_PW; ++i) {      // A piece = 8 rows x 128 B; wave w stages rows 24 w .. 24 w + 23
-      const int rl = 8 * (A_PW * wave + i) + (lane >> 3), c = (lane & 7) ^ Ge::a_swz(rl), row = m0 + rl;
-      a_k[i] = 4 * c;
-      a_off[i] = row < g.M ? ((unsigned)row * (unsigned)g.lda + 4u * c) * 4u : OOB;
-    }
-#pragma unroll
-    for (int i = 0; i < B_PW; ++i) {      // B piece = 16 rows x 64 B of one plane
-      const int q = wave * B_PW + i, p = q / (BN / 16), rl = 16 * (q % (BN / 16)) + (lane >> 2), c = (lane & 3) ^ Ge::b_swz(rl), row = n0 + rl;
-      b_k[i] = 8 * c;
-      b_off[i] = row < g.N ? (unsigned)(((long long)p * g.bplane + (long long)row * g.ldbp + 8 * c) * 2ll) : OOB;
-    }
-    auto piece = [&](int i, int k0, int buf, bool full) {
-      const unsigned st = lds0 + buf * STAGE;
-      if (i < A_PW) {
-        unsigned off = a_off[i] + 4u * (unsigned)k0;
-        if (!full) off = (k0 + a_k[i] < g.K) ? off : OOB;
-        g3f_dma16(a_rs, off, st + (A_PW * wave + i) * 1024);
-      } else {
-        unsigned off = b_off[i - A_PW] + 2u * (unsigned)k0;
-        if (!full) off = (k0 + b_k[i - A_PW] < g.ldbp) ? off : OOB;
-        g3f_dma16(b_rs, off, st + A_BYTES + (wave * B_PW + i - A_PW) * 1024);
-      }
-    };
-    auto is_full = [&](int k0) { return k0 + BK <= g.K && k0 + BK <= g.ldbp; };
-
-    g3g_f4 acc[3][CB];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < CB; ++j) acc[i][j] = g3g_f4{0.f, 0.f, 0.f, 0.f};
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int nt = (g.K + BK - 1) / BK;
-    auto slice = [&](int it, auto next_tag) {
-      constexpr bool NEXT = decltype(next_tag)::value;
-      const int k0n = (it + 1) * BK, bufn = (it + 1) & 1;
-      const bool fulln = is_full(k0n);
-      const unsigned char* st = smem + (it & 1) * STAGE;
-      const unsigned char* Bs = st + A_BYTES;
-      // the wave's three A fragments (16 rows x 32 k each), split once per slice
-      pf_bf16x8 a[3][3];
-#pragma unroll
-      for (int rb = 0; rb < 3; ++rb) {
-        const int rl = 48 * wm + 16 * rb + l15, sw = Ge::a_swz(rl);
-        const float4 v0 = *reinterpret_cast<const float4*>(st + rl * 128 + (((2 * kq) ^ sw) << 4));
-        const float4 v1 = *reinterpret_cast<const float4*>(st + rl * 128 + (((2 * kq + 1) ^ sw) << 4));
-        uint4 q0, q1, q2;
-        g3_split8(v0, v1, q0, q1, q2);
-        a[rb][0] = __builtin_bit_cast(pf_bf16x8, q0); a[rb][1] = __builtin_bit_cast(pf_bf16x8, q1); a[rb][2] = __builtin_bit_cast(pf_bf16x8, q2);
-      }
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        const int n = WN * wn + 16 * cb + l15;
-        const unsigned char* bp = Bs + n * 64 + ((kq ^ Ge::b_swz(n)) << 4);
-        const pf_bf16x8 b0 = *reinterpret_cast<const pf_bf16x8*>(bp);
-        const pf_bf16x8 b1 = *reinterpret_cast<const pf_bf16x8*>(bp + PLANE_B);
-        const pf_bf16x8 b2 = *reinterpret_cast<const pf_bf16x8*>(bp + 2 * PLANE_B);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-          // smallest terms first
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb][2], b0, acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb][1], b1, acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb][0], b2, acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb][1], b0, acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb][0], b1, acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb][0], b0, acc[rb][cb], 0, 0, 0);
-        }
-        if constexpr (NEXT) {
-#pragma unroll
-          for (int i = 0; i < NP; ++i)
-            if (i * CB / NP == cb) piece(i, k0n, bufn, fulln);
-        }
-      }
-    };
-#pragma unroll
-    for (int i = 0; i < NP; ++i) piece(i, 0, 0, is_full(0));
-    for (int it = 0; it + 1 < nt; ++it) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      slice(it, std::true_type{});
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    slice(nt - 1, std::false_type{});
-    __syncthreads();            // the operand stages are dead: LDS becomes the write-out staging area
-    // Write-out, 16 rows at a time per wave: accumulator layout of a 16x16 tile is row = 4 (lane >> 4) + r, col = lane & 15;
-    // through a private 16 x (WN + 4) strip, then whole rows as dwordx4.  Loads before stores (see pf_gemm3f_body).
-    {
-      constexpr int CS = WN + 4, Q = WN / 4, P = 16 * Q / 64, RP = 64 / Q;      // float4 per strip row; passes per strip; rows per pass
-      float* Cs = reinterpret_cast<float*>(smem) + wave * (16 * CS);
-      const int c4 = lane % Q, r0 = lane / Q, col = n0 + WN * wn + 4 * c4;
-      const bool cok = col < g.N;
-      const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (unsigned)g.M * (unsigned)g.ldc * 4u, 0x00020000);
-      const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == GEMM_EPI_MUL_DELU ? g.H : g.C), 0, (unsigned)g.M * (unsigned)(EPI == GEMM_EPI_MUL_DELU ? g.ldh : g.ldc) * 4u, 0x00020000);
-      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), hv[2][P];
-      auto load_h = [&](int rb, float4 (&dst)[P]) {
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const int row = m0 + 48 * wm + 16 * rb + r0 + RP * p;
-          dst[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rs, (int)((row < g.M && cok) ? ((unsigned)row * (unsigned)g.ldh + (unsigned)col) * 4u : OOB), 0, 0));
-        }
-      };
-      if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) { if (cok) b4 = *reinterpret_cast<const float4*>(g.bias + col); }
-      if (EPI == GEMM_EPI_MUL_DELU) load_h(0, hv[0]);
-#pragma unroll
-      for (int rb = 0; rb < 3; ++rb) {
-        if (rb > 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(4 * kq + r) * CS + 16 * cb + l15] = acc[rb][cb][r];
-        if (EPI == GEMM_EPI_MUL_DELU && rb + 1 < 3) load_h(rb + 1, hv[(rb + 1) & 1]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const int r = r0 + RP * p, row = m0 + 48 * wm + 16 * rb + r;
-          float4 v = *reinterpret_cast<const float4*>(&Cs[r * CS + 4 * c4]);
-          if (EPI == GEMM_EPI_BIAS || EPI == GEMM_EPI_BIAS_ELU) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-          if (EPI == GEMM_EPI_BIAS_ELU) { v.x = pf_elu(v.x); v.y = pf_elu(v.y); v.z = pf_elu(v.z); v.w = pf_elu(v.w); }
-          if (EPI == GEMM_EPI_MUL_DELU) {
-            const float4 h = hv[rb & 1][p];
-            v.x *= (h.x > 0.0f ? 1.0f : h.x + 1.0f); v.y *= (h.y > 0.0f ? 1.0f : h.y + 1.0f);
-            v.z *= (h.z > 0.0f ? 1.0f : h.z + 1.0f); v.w *= (h.w > 0.0f ? 1.0f : h.w + 1.0f);
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g3f_u4, v), c_rs, (int)((row < g.M && cok) ? ((unsigned)row * (unsigned)g.ldc + (unsigned)col) * 4u : OOB), 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-template <int BN, int EPI>
-__global__ __launch_bounds__(512, 1) void pf_gemm3g_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[G3gGeom<BN>::LDS];
-  pf_gemm3g_body<BN, EPI>(g, (int)blockIdx.x, (int)gridDim.x, smem);
-}
-template <int BN, int EPI>
-__global__ __launch_bounds__(512, 1) void pf_gemm3g_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[G3gGeom<BN>::LDS];
-  if ((int)blockIdx.x < nb0) pf_gemm3g_body<BN, EPI>(g0, (int)blockIdx.x, nb0, smem);
-  else pf_gemm3g_body<BN, EPI>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, smem);
-}
-template <int BN>
-static inline int pf_gemm3g_blocks(const GemmArgs& g) { return (((g.N + BN - 1) / BN) * ((g.M + G3G_BM - 1) / G3G_BM) + 7) / 8 * 8; }
-// variants 3 (192 x 256) and 4 (192 x 128)
-template <int EPI>
-static inline void pf_gemm3g_launch(const GemmArgs& g, hipStream_t s, int variant) {
-  if (variant == 3) hipLaunchKernelGGL((pf_gemm3g_kernel<256, EPI>), dim3(pf_gemm3g_blocks<256>(g)), dim3(512), 0, s, g);
-  else hipLaunchKernelGGL((pf_gemm3g_kernel<128, EPI>), dim3(pf_gemm3g_blocks<128>(g)), dim3(512), 0, s, g);
-}
-template <int EPI>
-static inline void pf_gemm3g_launch2(const GemmArgs& g0, const GemmArgs& g1, hipStream_t s, int variant) {
-  if (variant == 3) {
-    const int nb0 = pf_gemm3g_blocks<256>(g0), nb1 = pf_gemm3g_blocks<256>(g1);
-    hipLaunchKernelGGL((pf_gemm3g_kernel2<256, EPI>), dim3(nb0 + nb1), dim3(512), 0, s, g0, g1, nb0);
-  } else {
-    const int nb0 = pf_gemm3g_blocks<128>(g0), nb1 = pf_gemm3g_blocks<128>(g1);
-    hipLaunchKernelGGL((pf_gemm3g_kernel2<128, EPI>), dim3(nb0 + nb1), dim3(512), 0, s, g0, g1, nb0);
-  }
-}

@@ -1209,14 +1209,14 @@ int pf_gemm_test(int mode, int M, int N, int K, const float* A, const float* B, 
     else pf_gemm_launch<64, 64, AK, BK_, E, CS>(g, S, s);
   };
   using T = std::true_type; using F = std::false_type;
-  if (mode >= 30) {      // bf16x6 with LDS-DMA staging (pf_gemm3f.h); tile: 0 auto, 64 / 128 = columns per block
+  if (mode >= 30) {      // bf16x6 with LDS-DMA staging (pf_gemm3f.h); tile: -1 auto, 0 = 128 columns per block, 1 = 64
     const int Kp = (K + 7) & ~7;
     SplitJobs js; js.n = 1;
     js.j[0] = SplitJob{B, reinterpret_cast<unsigned short*>(ws), N, K, mode == 30 ? K : N, Kp, mode == 30 ? 0 : 1, (long long)N * Kp, 0};
     js.j[0].blocks = (int)(((long long)N * Kp + 255) / 256);
     hipLaunchKernelGGL(k_split_weights, dim3(js.j[0].blocks), dim3(256), 0, s, js);
     g.lda = K; g.ldb = K; g.Bp = reinterpret_cast<const unsigned short*>(ws); g.ldbp = Kp; g.bplane = (long long)N * Kp;
-    const int bn = tile >= 0 ? tile : -1;      // variant: 0 (128, 32), 1 (64, 32), 2 (128, 16); -1 auto
+    const int bn = tile >= 0 ? tile : -1;      // variant: 0 = 128 columns per block, 1 = 64; -1 auto
     if (mode == 30) {
       if (!pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(g)) { pf_set_error("pf_gemm_test: shape / alignment not eligible for the LDS-DMA kernel"); return 2; }
       pf_gemm3f_launch<GEMM_EPI_BIAS_ELU>(g, s, bn);

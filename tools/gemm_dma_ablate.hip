@@ -1,6 +1,6 @@
 // Diagnostic: what is the LDS-DMA bf16-split GEMM's (pf_gemm3f.h) time made of?  Built once per -DG3F_ABLATE mask by
 // tools/gemm_dma_ablate.sh; results of an ablated build are wrong by construction -- only times are read.
-//   gemm_dma_ablate MODE M N K BN [ZEROS] [PAIR]      MODE 0 FWD (x W^T + b, ELU), 1 BWD_X;  BN = kernel variant: 0 (128 columns, BK 32), 1 (64, 32), 2 (128, 16), -1 auto;
+//   gemm_dma_ablate MODE M N K BN [ZEROS] [PAIR]      MODE 0 FWD (x W^T + b, ELU), 1 BWD_X;  BN = kernel variant: 0 (128 columns), 1 (64), -1 auto;
 //   PAIR 1: two problems of this shape in one launch (as the PPO update issues the actor's and the critic's layer)
 #include <hip/hip_runtime.h>
 #include <cstdio>

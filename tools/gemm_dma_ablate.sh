@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   done
   wait
 else
-  for shape in "0 24576 256 512 0 0 1" "0 24576 256 512 3 0 1" "0 24576 256 512 4 0 1" "1 24576 512 256 0 0 1" "1 24576 512 256 3 0 1" "1 24576 512 256 4 0 1" "0 24576 512 148 0 0 1" "0 24576 512 148 3 0 1" "0 24576 512 148 4 0 1" "0 24576 128 256 1 0 1" "0 24576 128 256 4 0 1" "1 24576 256 128 0 0 1" "1 24576 256 128 3 0 1" "1 24576 256 128 4 0 1" ${BIG:+"0 4096 4096 4096 128"}; do
+  for shape in "0 24576 256 512 0 0 1" "0 24576 256 512 1 0 1" "1 24576 512 256 0 0 1" "0 24576 512 148 0 0 1" "0 24576 128 256 1 0 1" "1 24576 256 128 0 0 1" "1 24576 256 128 1 0 1" ${BIG:+"0 4096 4096 4096 0"}; do
     for m in $MASKS; do tools/_build/gemm_dma_ablate_$m $shape; done
   done
 fi
