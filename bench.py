@@ -199,8 +199,14 @@ def main():
         ev_pairs.append((s, e))
         return out
 
+    it_marks = []           # events at the head of every timed iteration (+ one at the end): per-iteration durations -> medians
+
     def iteration(obs, cobs, record):
         env.step = timed_step if record else orig_step
+        if record:
+            m = torch.cuda.Event(enable_timing=True)
+            m.record()
+            it_marks.append(m)
         obs, cobs, _ = runner.rollout(obs, cobs)
         if record:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -222,6 +228,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         obs, cobs = iteration(obs, cobs, True)
+    end_mark = torch.cuda.Event(enable_timing=True)
+    end_mark.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -238,6 +246,14 @@ def main():
         print(f"[bench] timed region done: {a.steps} iterations in {dt:.3f} s = {value:.0f} env-steps/s", file=sys.stderr, flush=True)
     step_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_pairs]))            # one fused env-step launch
     upd_ms = float(np.mean([s.elapsed_time(e) for s, e in up_pairs]))
+    # medians over the timed iterations, and the collection-only / learn-only rates.  Device-side durations (HIP
+    # events on the launch stream): iteration i = mark i -> mark i+1, collection = mark i -> update start, learn = the update.
+    marks = it_marks + [end_mark]
+    it_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(it_marks))]
+    col_ms = [it_marks[i].elapsed_time(up_pairs[i][0]) for i in range(len(it_marks))]
+    upd_all = [s.elapsed_time(e) for s, e in up_pairs]
+    med = lambda v: float(np.median(v))
+    per_iter_steps = a.num_envs * T
     finite = bool(torch.isfinite(runner.alg.params).all().item()) and bool(torch.isfinite(env.rew_buf).all().item())
     # the same loop once more with the dense layers on the plain fp32 MFMA kernels (v_mfma_f32_32x32x2_f32), reported beside
     # `value` so that the two arithmetic paths can be compared from one run (single GPU, default --gemm only)
@@ -325,7 +341,14 @@ def main():
                                               "frac": 6.0 * ach_tf / MFMA_BF16_PEAK_TFLOPS} if x6 else None),
                              "note": "algorithmic fp32 GEMM flops of one update / event-timed duration of the whole update phase, against the fp32 "
                                      "matrix peak; mfma_issued = the bf16 MFMA work actually issued (6 products per fp32 product) against the dense bf16 peak"},
-            "phase_ms": {"env_step_launch": step_ms, "ppo_update": upd_ms, "iteration": dt / a.steps * 1e3},
+            "phase_ms": {"env_step_launch": step_ms, "ppo_update": upd_ms, "iteration": dt / a.steps * 1e3,
+                         "rollout": float(np.mean(col_ms)), "median": {"iteration": med(it_ms), "rollout": med(col_ms), "ppo_update": med(upd_all),
+                                                                       "env_step_launch": med([s.elapsed_time(e) for s, e in ev_pairs])}},
+            "median_value": n_gpus * per_iter_steps / (med(it_ms) * 1e-3),
+            "collection_rate": {"value": n_gpus * per_iter_steps / (med(col_ms) * 1e-3), "unit": "env-steps/s",
+                                "note": "collection only: 24 x [policy forward + fused env step + transition store] + GAE, median iteration, this rank's device time"},
+            "learn_rate": {"value": n_gpus * per_iter_steps / (med(upd_all) * 1e-3), "unit": "env-steps/s",
+                           "note": "PPO update only (5 epochs x 4 minibatches), median iteration"},
         }
         if n_gpus == 1 and not a.no_cpu_baseline and not anymal:
             try:

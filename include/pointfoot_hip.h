@@ -351,7 +351,8 @@ int64_t ppo_workspace_floats(const PpoConfig* cfg);
 /* PPO.act: actor+critic forward on (obs, critic_obs), Normal(mu, std).sample(), log-prob, store
  * transition `t` (rsl_rl PPO.act + RolloutStorage.add_transitions).  d_actions_out (N,A).
  * The caller may rewrite d_params between rollouts (checkpoint load, broadcast); derived copies of the weights are refreshed
- * at t == 0 and by every other entry point that runs a dense layer, not between the transitions of one rollout. */
+ * at t == 0, on the first dense call after ppo_bind_buffers or an optimiser step whatever its t, and by every other entry point
+ * that runs a dense layer -- not between the transitions of one rollout after an external rewrite of d_params. */
 int ppo_act(PpoAlg* alg, int32_t t, const float* d_obs, const float* d_critic_obs, float* d_actions_out,
             int64_t sample_counter, const float* d_inject_normal, void* stream);
 /* actor forward only (act_inference / get_inference_policy) */

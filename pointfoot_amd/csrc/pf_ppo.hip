@@ -843,6 +843,7 @@ struct PpoAlg {
   size_t w_xa, w_xc, w_act, w_oldlogp, w_oldmu, w_oldsig, w_adv, w_ret, w_oldval;
   int ld_xa = 0, ld_xc = 0;   // row strides of the minibatch observation copies: widths rounded up to 4 floats (16-byte rows: dwordx4 loads)
   size_t w_perm[9];        // the nine storage arrays of an update in minibatch order (all T*N rows): ppo_begin_update
+  bool planes_valid = false;   // the bf16 weight planes match d_params as this handle last saw them (cleared by bind / optimiser step)
   bool permuted = false;   // w_perm holds the current permutation (set by ppo_begin_update, dropped by the next rollout)
   size_t w_ha[PPO_MAX_LAYERS], w_hc[PPO_MAX_LAYERS];   // activations per layer output (last = head output)
   size_t w_wp[2][PPO_MAX_LAYERS], w_wtp[2][PPO_MAX_LAYERS];      // bf16 planes of W (and W^T) per hidden layer, in floats of workspace
@@ -973,6 +974,7 @@ static void split_weights(PpoAlg* a, hipStream_t s) {
     }
   }
   hipLaunchKernelGGL(k_split_weights, dim3(blocks), dim3(256), 0, s, js);
+  a->planes_valid = true;
 }
 // B operand of layer i as planes: the forward GEMM reads W [out][in], the data-gradient GEMM W^T [in][out]
 static void use_planes(PpoAlg* a, GemmArgs& g, int net, int layer, bool transposed) {
@@ -1337,7 +1339,7 @@ int ppo_bind_buffers(PpoAlg* a, const PpoBuffers* b) {
                        b->d_values, b->d_returns, b->d_advantages, b->d_log_prob, b->d_mu, b->d_sigma, b->d_perm, b->d_workspace, b->d_scalars};
   for (const void* p : req) if (!p) { pf_set_error("ppo_bind_buffers: a required buffer is NULL"); return 1; }
   if (b->workspace_floats < (int64_t)a->w_total) { pf_set_error("ppo_bind_buffers: workspace too small (see ppo_workspace_floats)"); return 1; }
-  a->b = *b; a->bound = true;
+  a->b = *b; a->bound = true; a->planes_valid = false;
   return 0;
 }
 
@@ -1350,7 +1352,11 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   hipStream_t s = (hipStream_t)stream;
   const int N = c.num_envs, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   float* ws = a->b.d_workspace;
-  if (t == 0) { split_weights(a, s); a->permuted = false; }      // parameters only change between rollouts (optimiser step, checkpoint load, broadcast); a new rollout invalidates the permuted copy of the storage
+  // Parameters change between rollouts (optimiser step, checkpoint load, broadcast): the planes are rebuilt at the head of every
+  // rollout, and whenever this handle knows them stale (first dense call after create / bind, an optimiser step since).  A new
+  // rollout also invalidates the permuted copy of the storage.
+  if (t == 0 || !a->planes_valid) split_weights(a, s);
+  if (t == 0) a->permuted = false;
   hipStream_t s2 = a->paired ? s : ppo_fork(a, s);
   size_t tn = (size_t)t * N;
   if (a->fused_heads) {
@@ -1542,6 +1548,7 @@ int ppo_minibatch_apply(PpoAlg* a, void* stream) {
                      c.desired_kl, c.max_grad_norm, a->b.d_scalars);
   hipLaunchKernelGGL(k_adam, dim3(RED_BLOCKS), dim3(256), 0, s, a->nparams, a->b.d_params, a->b.d_grads, a->b.d_adam_m, a->b.d_adam_v, gscale,
                      c.adam_beta1, c.adam_beta2, c.adam_eps, a->b.d_scalars);
+  a->planes_valid = false;
   PPO_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -27,9 +27,10 @@ class _EpisodeInfo(dict):
     `terrain_level`, as 0-d device tensors.  Filled lazily from the step's statistics slot on first access, so a
     rollout that nobody logs costs no extra kernels and nothing ever synchronises with the host."""
 
-    def __init__(self, fill):
+    def __init__(self, fill, raw=None):
         super().__init__()
         self._fill = fill
+        self.raw = raw      # () -> dict(names, sums, count, scale, mean_extras, const_extras): what a cross-rank reduction needs (dp.reduce_episode_infos)
 
     def _ensure(self):
         if self._fill is not None:
@@ -202,6 +203,7 @@ class HipEnv:
         if len(env_ids) == 0:
             return
         if len(env_ids) == self.num_envs:
+            self._next_stats_slot()       # own slot: the previous step's lazily-read statistics stay intact, extras read this one
             _abi.check(self._lib.pf_reset_all(self._h, self.common_step_counter, None, self._stream()), self._lib)
         else:
             # a subset (scripted single-env resets, scripts/simulate_trajectory.py:72-97): same launch, masked on the device
@@ -219,10 +221,16 @@ class HipEnv:
             return
         i = self._sum_names.index("tracking_lin_vel")
         stats = self._reset_stats
-        cnt = float(stats[_abi.PF_MAX_REWARDS].item())        # host sync, once per max_episode_length steps
+        pair = torch.stack([stats[i], stats[_abi.PF_MAX_REWARDS]])
+        if self.world_size > 1:
+            # every rank must take the same decision (the command range is one number for the whole job): sums and counts of
+            # all shards, i.e. the mean one process with all the envs would see.  Once per max_episode_length steps.
+            from pointfoot_amd.rsl_rl import dp
+            pair = dp.allreduce_sum(pair.clone())
+        tot, cnt = (float(v) for v in pair.tolist())         # host sync, once per max_episode_length steps
         if cnt <= 0:
             return
-        mean_sum = float(stats[i].item()) / cnt
+        mean_sum = tot / cnt
         if mean_sum / self.max_episode_length > 0.8 * self.reward_scales["tracking_lin_vel"]:
             r = self.command_ranges["lin_vel_x"]
             mc = self.cfg.commands.max_curriculum
@@ -249,7 +257,13 @@ class HipEnv:
     def _next_stats_slot(self):
         """rotate the per-step statistics slot (ring of 64: valid for the iteration the runner logs)"""
         self._stats_slot = (self._stats_slot + 1) % self._stats_ring.shape[0]
+        self._bind_stats_slot()
+
+    def _bind_stats_slot(self):
+        """point the kernel AND the host copy of the buffer table at the current slot: every later pf_bind_buffers (friction,
+        measured heights, contact set) hands the whole table over again and must not resurrect an older pointer"""
         self._reset_stats = self._stats_ring[self._stats_slot]
+        self._bufs.d_reset_stats = _native.ptr(self._reset_stats)
         _abi.check(self._lib.pf_set_reset_stats(self._h, self._reset_stats.data_ptr()), self._lib)
         nxt = self._stats_ring[(self._stats_slot + 1) % self._stats_ring.shape[0]]
         _abi.check(self._lib.pf_set_reset_stats_next(self._h, nxt.data_ptr()), self._lib)
@@ -267,9 +281,11 @@ class HipEnv:
         slots than steps between two logs (the step kernel clears the slot after the one it fills)."""
         need = int(num_steps) + 2
         if self._stats_ring.shape[0] < need:
+            old = self._stats_ring      # stays alive until the kernel has been pointed at the new ring
             self._stats_ring = torch.zeros(need, _abi.PF_STATS_FLOATS, device=self.device, dtype=torch.float)
             self._stats_slot = 0
-            self._reset_stats = self._stats_ring[0]
+            self._bind_stats_slot()
+            del old
 
     def _fill_extras(self):
         # reference :276-288
@@ -287,7 +303,11 @@ class HipEnv:
             if self.cfg.commands.curriculum:
                 ep["max_command_x"] = self.command_ranges["lin_vel_x"][1]
             return ep
-        self.extras["episode"] = _EpisodeInfo(fill)
+        def raw():
+            mean_extras = {"terrain_level": torch.mean(levels.float())} if curriculum else {}
+            const_extras = {"max_command_x": self.command_ranges["lin_vel_x"][1]} if self.cfg.commands.curriculum else {}
+            return dict(names=names, sums=stats, count=stats[_abi.PF_MAX_REWARDS], scale=T, mean_extras=mean_extras, const_extras=const_extras)
+        self.extras["episode"] = _EpisodeInfo(fill, raw)
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf
 

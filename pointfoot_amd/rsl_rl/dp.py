@@ -45,6 +45,54 @@ def allreduce_adv_stats(stats3):
     return stats3
 
 
+def allreduce_sum(t):
+    """in-place sum over ranks of a small statistics tensor (episode sums and counts); a no-op on one rank"""
+    rank, ws = world()
+    if ws > 1:
+        dist.all_reduce(t)
+    return t
+
+
+def reduce_episode_infos(ep_infos, device):
+    """The iteration's `extras["episode"]` entries -> one dict of floats, as ONE process with all the envs would log it
+    (reference: legged_gym/envs/pointfoot/point_foot.py:276-285 takes the mean over the envs reset on a step; rsl_rl's
+    runner averages those per-step means over the iteration).  Each rank holds, per step, the SUMS over its own reset envs
+    and their COUNT (`_EpisodeInfo.raw()`); summing both over ranks before dividing is the count-weighted mean across shards
+     -- averaging the ranks' means would weight a rank with one reset env like a rank with a hundred.
+    Collective: every rank must call it (with the same number of entries) when world_size > 1."""
+    import torch
+    rank, ws = world()
+    out = {}
+    raws = [e.raw() for e in ep_infos if hasattr(e, "raw") and e.raw is not None]
+    if raws and len(raws) == len(ep_infos):
+        names = raws[0]["names"]
+        n = len(names)
+        extra_keys = sorted(raws[0]["mean_extras"].keys())
+        M = torch.stack([torch.cat([r["sums"][:n].reshape(-1).float(), r["count"].reshape(1).float(),
+                                    torch.stack([torch.as_tensor(r["mean_extras"][k], dtype=torch.float, device=r["sums"].device).reshape(()) for k in extra_keys]).reshape(-1)
+                                    if extra_keys else r["sums"].new_zeros(0)]) for r in raws]).to(device)
+        allreduce_sum(M)
+        cnt = M[:, n:n + 1]
+        per_step = M[:, :n] / cnt / raws[0]["scale"]          # NaN on steps where no env was reset anywhere
+        vals = torch.nanmean(per_step, dim=0)
+        for i, k in enumerate(names):
+            out["rew_" + k] = float(vals[i])
+        for j, k in enumerate(extra_keys):
+            out[k] = float(M[:, n + 1 + j].mean() / ws)         # per-rank means over equal shard sizes
+        for k, v in raws[0]["const_extras"].items():
+            out[k] = float(v)
+        return out
+    # entries without raw statistics (another VecEnv): per-rank values, averaged over steps; ranks are averaged unweighted
+    if ep_infos:
+        for key in ep_infos[0]:
+            vals = [ep[key] for ep in ep_infos if key in ep]
+            v = torch.nanmean(torch.stack([torch.as_tensor(x, dtype=torch.float).reshape(()).to(device) for x in vals])).reshape(1)
+            if ws > 1:
+                v = torch.nan_to_num(v); dist.all_reduce(v); v = v / ws
+            out[key] = float(v)
+    return out
+
+
 def init_from_env(backend="nccl"):
     """torchrun-style environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():

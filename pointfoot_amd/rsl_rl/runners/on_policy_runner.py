@@ -13,6 +13,7 @@ from collections import deque
 import torch
 import torch.distributed as dist
 
+from pointfoot_amd.rsl_rl import dp
 from pointfoot_amd.rsl_rl.algorithms import PPO
 from pointfoot_amd.rsl_rl.modules import ActorCritic
 
@@ -63,7 +64,7 @@ class OnPolicyRunner:
             obs, privileged_obs, rewards, dones, infos = env.step(actions)
             critic_obs = privileged_obs if privileged_obs is not None else obs
             alg.process_env_step(rewards, dones, infos)
-            if self.log_dir is not None and 'episode' in infos:
+            if (self.log_dir is not None or self.world_size > 1) and 'episode' in infos:
                 ep_infos.append(infos['episode'])
             # (episode return / length bookkeeping happens inside ppo_process_env_step, on the device)
         alg.compute_returns(critic_obs)
@@ -97,8 +98,13 @@ class OnPolicyRunner:
             torch.cuda.synchronize(self.device)
             stop = time.time()
             learn_time = stop - start
-            if self.rank == 0 and (it % self.log_interval == 0):
-                self.log(locals())
+            if it % self.log_interval == 0:
+                # every rank takes part: episode statistics are reduced over all env shards (count-weighted), rank 0 prints
+                ep_means = dp.reduce_episode_infos(ep_infos, self.device)
+                ep_totals = dp.allreduce_sum(self._ep_stats.clone()).tolist()
+                self._ep_stats.zero_()
+                if self.rank == 0:
+                    self.log(locals())
             if self.log_dir is not None and self.rank == 0 and it % self.save_interval == 0:
                 self.save(os.path.join(self.log_dir, 'model_{}.pt'.format(it)))
             ep_infos.clear()
@@ -111,17 +117,14 @@ class OnPolicyRunner:
         self.tot_timesteps += n_total
         self.tot_time += locs['collection_time'] + locs['learn_time']
         iteration_time = locs['collection_time'] + locs['learn_time']
-        stats = self._ep_stats.tolist()
-        self._ep_stats.zero_()
+        stats = locs['ep_totals']           # [sum of returns, sum of lengths, count] of the episodes finished since the last log, all ranks
         if stats[2] > 0:
             self.rewbuffer.append(stats[0] / stats[2])
             self.lenbuffer.append(stats[1] / stats[2])
         ep_string = ''
-        if locs['ep_infos']:
-            for key in locs['ep_infos'][0]:
-                vals = [ep[key] for ep in locs['ep_infos'] if key in ep]
-                # steps on which no env was reset carry NaN (no fresh episode entry in the reference): mean over the others
-                value = float(torch.nanmean(torch.stack([torch.as_tensor(v, dtype=torch.float).reshape(()).to(self.device) for v in vals])))
+        if locs['ep_means']:
+            # steps on which no env was reset anywhere carry NaN (no fresh episode entry in the reference): mean over the others
+            for key, value in locs['ep_means'].items():
                 if self.writer:
                     self.writer.add_scalar('Episode/' + key, value, locs['it'])
                 ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""

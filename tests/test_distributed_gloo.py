@@ -96,3 +96,47 @@ def test_data_parallel_gradient_matches_single_process(tmp_path):
     torch.testing.assert_close(r["gmean"], ac.flat_grad(), atol=1e-6, rtol=1e-4)
     assert abs(r["kl"] - kl.item()) < 1e-6
     torch.testing.assert_close(r["stats"], torch.tensor([3.0, 4.0, 6.0]))
+
+
+class _FakeInfo(dict):
+    """stand-in for hip_env._EpisodeInfo: the per-step sums over this rank's reset envs, their count, a per-rank mean"""
+    def __init__(self, sums, count, level):
+        super().__init__()
+        self._r = dict(names=["a", "b"], sums=torch.tensor(sums + [0.0]), count=torch.tensor(float(count)), scale=2.0,
+                       mean_extras={"terrain_level": torch.tensor(level)}, const_extras={"max_command_x": 1.5})
+        self.raw = lambda: self._r
+
+
+def _ep_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pointfoot_amd.rsl_rl import dp
+    # step 0: rank 0 reset 1 env (sums 2, 4), rank 1 reset 3 envs (sums 10, 20); step 1: nobody reset anything;
+    # step 2: only rank 1 reset (2 envs)
+    infos = [[_FakeInfo([2.0, 4.0], 1, 1.0), _FakeInfo([0.0, 0.0], 0, 1.0), _FakeInfo([0.0, 0.0], 0, 1.0)],
+             [_FakeInfo([10.0, 20.0], 3, 3.0), _FakeInfo([0.0, 0.0], 0, 3.0), _FakeInfo([6.0, 8.0], 2, 3.0)]][rank]
+    red = dp.reduce_episode_infos(infos, "cpu")
+    tot = dp.allreduce_sum(torch.tensor([1.0 + rank, 10.0, 2.0]))
+    if rank == 0:
+        torch.save(dict(red=red, tot=tot), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_episode_statistics_are_count_weighted_across_ranks(tmp_path):
+    """the logged episode means are those of ONE process with all envs -- sums and counts are reduced over the
+    shards before dividing (a rank with 1 reset env must not weigh like a rank with 3)."""
+    out = str(tmp_path / "ep.pt")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_ep_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=True)
+    red = r["red"]
+    # step 0: (2 + 10) / 4 / scale = 1.5, step 2: 6 / 2 / 2 = 1.5 (a), step 1 is NaN and skipped
+    assert abs(red["rew_a"] - 1.5) < 1e-6
+    assert abs(red["rew_b"] - ((4 + 20) / 4 / 2 + 8 / 2 / 2) / 2) < 1e-6
+    assert abs(red["terrain_level"] - 2.0) < 1e-6 and red["max_command_x"] == 1.5
+    torch.testing.assert_close(r["tot"], torch.tensor([3.0, 20.0, 4.0]))
+    # one rank alone: the plain per-step means
+    from pointfoot_amd.rsl_rl import dp
+    solo = dp.reduce_episode_infos([_FakeInfo([2.0, 4.0], 1, 1.0), _FakeInfo([0.0, 0.0], 0, 1.0)], "cpu")
+    assert abs(solo["rew_a"] - 1.0) < 1e-6 and abs(solo["rew_b"] - 2.0) < 1e-6

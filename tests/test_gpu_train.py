@@ -223,6 +223,21 @@ def test_partial_reset_joint_friction_and_stats_ring():
     assert env._stats_ring.shape[0] >= runner.num_steps_per_env + 2
     env.ensure_stats_ring(100)
     assert env._stats_ring.shape[0] == 102
+    # a re-bind after the ring grew must not resurrect the old ring's pointer (the buffer table is handed over whole
+    # by update_frictions / measured_heights / bind_contact_set); a full reset then lands in the slot the extras read
+    ring_ptrs = (env._stats_ring.data_ptr(), env._stats_ring.data_ptr() + env._stats_ring.numel() * 4)
+    env.update_frictions([1.0] * 6, 2, 0)
+    _ = env.bind_contact_set()
+    assert ring_ptrs[0] <= int(env._bufs.d_reset_stats or 0) < ring_ptrs[1]
+    prev = env._reset_stats
+    env.reset()
+    torch.cuda.synchronize()
+    assert ring_ptrs[0] <= env._reset_stats.data_ptr() < ring_ptrs[1] and env._reset_stats.data_ptr() == int(env._bufs.d_reset_stats)
+    assert env._reset_stats.data_ptr() != prev.data_ptr()          # the reset and the step after it took slots of their own
+    from pointfoot_amd import _abi as abi
+    slots = env._stats_ring[:, abi.PF_MAX_REWARDS]
+    assert float(slots.max()) == n                                  # reset_idx(all): every env counted, in a slot of this ring
+    assert float(env._stats_ring.sum(dim=1).ne(0).sum()) <= 2       # nothing leaked into other slots
     env.step(a)
     torch.cuda.synchronize()
 
