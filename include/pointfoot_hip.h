@@ -40,6 +40,8 @@ extern "C" {
 #define PF_MAX_CAPS 16         /* collision capsules (pairs of equal-radius spheres on one body; a lone sphere is a capsule of length 0) */
 #define PF_MAX_PAIRS 32        /* self-collision capsule pairs */
 #define PF_STATS_FLOATS (PF_MAX_REWARDS + 4)
+#define PF_STAT_CAP_HITS (PF_MAX_REWARDS + 1)     /* d_reset_stats: (env, substep) pairs of this launch with more active contact candidates than the solver keeps */
+#define PF_STAT_CAP_DROPPED (PF_MAX_REWARDS + 2)  /* d_reset_stats: contact candidates dropped by that cap in this launch */
 /* actuator network `LSTMsea` (resources/actuator_nets/anydrive_v3_lstm.pt): in_scale(2), out_scale(1), LSTM(2->8) x 2 layers
  * (PyTorch gate order i,f,g,o), Linear(8->1).  Flat parameter block handed over in d_actuator_params: */
 #define PF_ACT_IN_SCALE 0
@@ -226,7 +228,8 @@ typedef struct PfBuffers {
   const float* d_terrain_origins;  /* (max_terrain_level, terrain_num_cols, 3) or NULL */
   const float* d_actuator_params; /* LeggedRobot + actuator net: PF_ACT_PARAMS floats (see PF_ACT_* offsets) or NULL */
   float* d_reset_stats;        /* (PF_STATS_FLOATS,): [i] = sum of episode_sums[i] over the envs reset this step
-                                  (point_foot.py:276-280), [PF_MAX_REWARDS] = number of envs reset; zeroed by pf_step */
+                                  (point_foot.py:276-280), [PF_MAX_REWARDS] = number of envs reset, [PF_STAT_CAP_HITS] /
+                                  [PF_STAT_CAP_DROPPED] = contact-cap diagnostics (HIP path only); zeroed by pf_step */
   const float* d_joint_friction; /* (N, nd) Coulomb joint friction torque per DOF (update_frictions, point_foot.py:103-108:
                                   dof_props["friction"]) or NULL = none */
   uint64_t* d_contact_set;     /* (N, decimation, 3) or NULL.  Diagnostic output for parity tests, the discrete decisions of

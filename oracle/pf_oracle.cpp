@@ -209,7 +209,9 @@ template <typename R> inline Sp6<R> spI_mul(const SpI<R>& I, const Sp6<R>& v) {
   return {symmul(I.I, v.a) + cross(I.h, v.l), I.m * v.l - cross(I.h, v.a)};
 }
 
-const int MAXC = 6;                              // contacts kept per robot (first active in sphere order)
+const int MAXC_POINTFOOT = 6, MAXC_QUAD = 10;    // contacts kept per robot (first active in sphere order); the quadruped keeps 10:
+                                                 // 4 feet x (floor + riser face), see pf_step_kernel.h PF_MAXC / PF_MAXC_QUAD
+const int MAXC = MAXC_QUAD;                      // array bound
 const int MAXROWS = 3 * MAXC + PF_MAX_DOF;
 const int NVMAX = 6 + PF_MAX_DOF;
 
@@ -475,7 +477,8 @@ void physics_substep(const Ctx& x, float* S, bool apply_ext, int env, int sub, i
     hit[s] = Terrain<R>::query(x, ix0, iy0, pos.x + sphc[s].x, pos.y + sphc[s].y, pos.z + sphc[s].z, (R)m.sph_radius[s]);
   }
   const int ncand = 2 * m.nsph + (c.self_collisions ? m.npair : 0);
-  for (int cand = 0; cand < ncand && ncon < MAXC; ++cand) {
+  const int maxc = c.env_kind == PF_KIND_LEGGED_ROBOT ? MAXC_QUAD : MAXC_POINTFOOT;
+  for (int cand = 0; cand < ncand && ncon < maxc; ++cand) {
     int i, ib = -1; V3<R> n, xc; R dist;
     if (cand < 2 * m.nsph) {
       const int s = cand < m.nsph ? cand : cand - m.nsph;

@@ -19,6 +19,8 @@ PF_MAX_CAPS = 16
 PF_MAX_PAIRS = 32
 PPO_MAX_LAYERS = 4
 PF_STATS_FLOATS = PF_MAX_REWARDS + 4
+PF_STAT_CAP_HITS = PF_MAX_REWARDS + 1
+PF_STAT_CAP_DROPPED = PF_MAX_REWARDS + 2
 PF_ACT_PARAMS = 972
 PF_KIND_POINTFOOT, PF_KIND_LEGGED_ROBOT = 0, 1
 

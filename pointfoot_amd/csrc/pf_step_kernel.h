@@ -11,7 +11,10 @@
 #include "pf_simt.h"
 
 #define PF_REC_MAX 160
-#define PF_MAXC 6          /* contacts kept per robot (first active in sphere order: feet first) */
+#define PF_MAXC 6          /* contacts kept per robot (first active in sphere order: feet first): PointFoot.  The quadruped instance keeps
+                              PF_MAXC_QUAD = 10 (4 feet x floor + riser face, and two more for a shank or the base): measured on the curriculum field, 0.68 % of its (env, substep)
+                              pairs had more than 6 active candidates, PointFoot's 3.4e-5 (profiles/r3_contact_cap.txt) */
+#define PF_MAXC_QUAD 10
 #define PF_MAX_CHAINS 8
 #define PF_MAX_CHAIN_DEPTH 8
 #define PF_KSPH 24         /* collision spheres staged per robot (PointFoot instance; the quadruped instance uses 32) */
@@ -200,7 +203,8 @@ struct PfKernel {
   static constexpr int REC_MAX = LR ? 704 : PF_REC_MAX;
   static constexpr int NV = 6 + ND;
   static constexpr int NVP = NV | 1;          // odd row stride: per-lane rows hit distinct LDS banks
-  static constexpr int MAXC = PF_MAXC;
+  static constexpr int MAXC = LR ? PF_MAXC_QUAD : PF_MAXC;
+  static constexpr int CREG = MAXC < 6 ? MAXC : 6;      // contact rows the PGS sweep holds in registers; the rest stay in LDS
   // self-collision capsules / capsule pairs this instance is built for (PointFoot: 2 legs x 4 links; the LeggedRobot tasks
   // of the reference switch self-collision off, anymal_c_rough_config.py:77)
   static constexpr int KC = LR ? 1 : 8, KP = LR ? 1 : 16;
@@ -852,6 +856,9 @@ struct PfKernel {
       if (cand_dist(cand) < c.contact_offset) { if (ncon < MAXC) sh.con_cand[ncon] = cand; ++ncon; cset |= 1ull << cand; }
 #endif
     if (ncon > MAXC) {      // candidates beyond the cap are not contacts: drop them from the reported set
+      // ... and count the event: [PF_STAT_CAP_HITS] (env, substep) pairs with more active candidates than the solver keeps,
+      // [PF_STAT_CAP_DROPPED] the candidates dropped (tools/train_check.py reports the fraction; profiles/r3_contact_cap.txt)
+      PF_ONE { if (B.d_reset_stats) { PF_ATOMIC_ADD(B.d_reset_stats + PF_STAT_CAP_HITS, 1.0f); PF_ATOMIC_ADD(B.d_reset_stats + PF_STAT_CAP_DROPPED, (float)(ncon - MAXC)); } }
       unsigned long long kept = 0ull, rest = cset;
       for (int t = 0; t < MAXC; ++t) { kept |= rest & (~rest + 1ull); rest &= rest - 1ull; }
       cset = kept; ncon = MAXC;
@@ -994,9 +1001,9 @@ struct PfKernel {
       // (J = +-e_k is rebuilt from lim_dof / lim_side, W and the impulse are read where they lie) -- 24 VGPRs the
       // quadruped kernel does not have (ANYmal's joints are continuous: no limit row is ever active there)
       constexpr int LREG = ND <= 6 ? ND : 4;
-      float jc[MAXC][3], wc[MAXC][3], lc[MAXC][3], jl[LREG], wl[LREG], ll[LREG];
+      float jc[CREG][3], wc[CREG][3], lc[CREG][3], jl[LREG], wl[LREG], ll[LREG];
 #pragma unroll
-      for (int ci = 0; ci < MAXC; ++ci)
+      for (int ci = 0; ci < CREG; ++ci)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           const bool on = ci < ncon;
@@ -1011,25 +1018,38 @@ struct PfKernel {
         wl[li] = (on && tv) ? sh.W[CROWS + li][tl] : 0.0f;
         ll[li] = on ? sh.lam[CROWS + li] : 0.0f;
       }
+      // one contact's block update (normal, then the two friction directions with the cone projection); j / w: this lane's
+      // components of the three rows, l: the three impulses (uniform)
+      auto contact_update = [&](int ci, const float (&j)[3], const float (&w)[3], float (&l)[3]) {
+        const int r0 = 3 * ci;
+        const float u0 = rsum(j[0] * v), u1 = rsum(j[1] * v), u2 = rsum(j[2] * v);
+        const float l0 = l[0], l1o = l[1], l2o = l[2];
+        const float ln = fmaxf(0.0f, l0 + (sh.rb[r0] - u0) * sh.rAinv[r0]);
+        const float d0 = ln - l0;
+        const float u1c = u1 + sh.cA[ci][3] * d0;
+        float l1 = l1o - u1c * sh.rAinv[r0 + 1];
+        const float d1p = l1 - l1o;
+        const float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
+        float l2 = l2o - u2c * sh.rAinv[r0 + 2];
+        const float lim = mu * ln, nt = pf_sqrt(l1 * l1 + l2 * l2);
+        if (nt > lim) { float sc = nt > 0.0f ? lim * pf_rcp(nt) : 0.0f; l1 *= sc; l2 *= sc; }
+        const float d1 = l1 - l1o, d2 = l2 - l2o;
+        v += w[0] * d0 + w[1] * d1 + w[2] * d2;
+        l[0] = ln; l[1] = l1; l[2] = l2;
+      };
       for (int it = 0; it < c.solver_iterations; ++it) {
 #pragma unroll
-        for (int ci = 0; ci < MAXC; ++ci) {
-          if (ci < ncon) {
-            const int r0 = 3 * ci;
-            const float u0 = rsum(jc[ci][0] * v), u1 = rsum(jc[ci][1] * v), u2 = rsum(jc[ci][2] * v);
-            const float l0 = lc[ci][0], l1o = lc[ci][1], l2o = lc[ci][2];
-            const float ln = fmaxf(0.0f, l0 + (sh.rb[r0] - u0) * sh.rAinv[r0]);
-            const float d0 = ln - l0;
-            const float u1c = u1 + sh.cA[ci][3] * d0;
-            float l1 = l1o - u1c * sh.rAinv[r0 + 1];
-            const float d1p = l1 - l1o;
-            const float u2c = u2 + sh.cA[ci][6] * d0 + sh.cA[ci][7] * d1p;
-            float l2 = l2o - u2c * sh.rAinv[r0 + 2];
-            const float lim = mu * ln, nt = pf_sqrt(l1 * l1 + l2 * l2);
-            if (nt > lim) { float sc = nt > 0.0f ? lim * pf_rcp(nt) : 0.0f; l1 *= sc; l2 *= sc; }
-            const float d1 = l1 - l1o, d2 = l2 - l2o;
-            v += wc[ci][0] * d0 + wc[ci][1] * d1 + wc[ci][2] * d2;
-            lc[ci][0] = ln; lc[ci][1] = l1; lc[ci][2] = l2;
+        for (int ci = 0; ci < CREG; ++ci) {
+          if (ci < ncon) contact_update(ci, jc[ci], wc[ci], lc[ci]);
+        }
+        if constexpr (CREG < MAXC) {
+          for (int ci = CREG; ci < ncon; ++ci) {      // contacts 7, 8 (quadruped): rows and impulses read where they lie in LDS
+            float j3[3], w3[3], l3[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { j3[d] = tv ? sh.J[3 * ci + d][tl] : 0.0f; w3[d] = tv ? sh.W[3 * ci + d][tl] : 0.0f; l3[d] = sh.lam[3 * ci + d]; }
+            contact_update(ci, j3, w3, l3);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sh.lam[3 * ci + d] = l3[d];      // every lane stores the same impulse: no barrier needed
           }
         }
 #pragma unroll
@@ -1059,7 +1079,7 @@ struct PfKernel {
       if (PF_LANE_ID < NV) sh.vel[PF_LANE_ID] = v;
       PF_ONE {
 #pragma unroll
-        for (int ci = 0; ci < MAXC; ++ci) if (ci < ncon) { sh.lam[3 * ci] = lc[ci][0]; sh.lam[3 * ci + 1] = lc[ci][1]; sh.lam[3 * ci + 2] = lc[ci][2]; }
+        for (int ci = 0; ci < CREG; ++ci) if (ci < ncon) { sh.lam[3 * ci] = lc[ci][0]; sh.lam[3 * ci + 1] = lc[ci][1]; sh.lam[3 * ci + 2] = lc[ci][2]; }
 #pragma unroll
         for (int li = 0; li < LREG; ++li) if (li < nlim) sh.lam[CROWS + li] = ll[li];
       }

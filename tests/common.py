@@ -325,3 +325,28 @@ class EmuMirror:
 
 if os.environ.get("PF_TEST_EMU") == "1":
     HipMirror = EmuMirror
+
+
+def record_parity(test, **measured):
+    """Leave what a `-m gpu` parity test MEASURED (flipped-decision fractions, allowance counts, worst GEMM error / bound ...)
+    where the GPU run's caller can see it: one JSON object per test in gpurun_out/parity_fractions.json (pytest -q swallows
+    prints).  The end-of-round copy is committed as profiles/r<N>_parity_fractions.json.  Host-emulation rehearsals do not write."""
+    import json
+    if os.environ.get("PF_TEST_EMU") == "1":
+        return
+    path = os.environ.get("PF_PARITY_JSON", os.path.join(ROOT, "gpurun_out", "parity_fractions.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        try:
+            with open(path) as f:
+                data = json.load(f)
+        except (OSError, ValueError):
+            data = {}
+        clean = {}
+        for k, v in measured.items():
+            clean[k] = v.item() if hasattr(v, "item") else v
+        data[test] = clean
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

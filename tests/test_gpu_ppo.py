@@ -178,7 +178,7 @@ def test_gemm_shapes_against_torch():
             torch.testing.assert_close(out, ref.actor(x), atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("path", ["fp32_mfma", "bf16x6", "bf16x6_planes"])
+@pytest.mark.parametrize("path", ["fp32_mfma", "bf16x6", "bf16x6_planes", "bf16x6_dma"])
 @pytest.mark.parametrize("mode", [0, 1, 2], ids=["fwd_bias_elu", "bwd_x_delu", "bwd_w_splitk_colsum"])
 def test_gemm_kernel_family_on_ragged_shapes(mode, path):
     """Both GEMM families through the test hook -- the fp32 MFMA kernels (pf_gemm.h) and the fp32-by-exact-bf16-split
@@ -186,7 +186,7 @@ def test_gemm_kernel_family_on_ragged_shapes(mode, path):
     lengths that are not multiples of the tile, of 4 (scalar loads and write-out) or of the k-slice, single-row
     problems, and split-K with a ragged last split.  Reference: FLOAT64 matmul; the tolerance is the float32 rounding
     budget of a length-K dot product and is THE SAME for both paths (the split drops only terms below 2^-23 |a b|)."""
-    if path == "bf16x6_planes" and mode == 2:
+    if path in ("bf16x6_planes", "bf16x6_dma") and mode == 2:
         pytest.skip("the weight gradient has no pre-split operand (both operands are activations)")
     lib = common._abi.load()
     lib.pf_gemm_test.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
@@ -195,10 +195,14 @@ def test_gemm_kernel_family_on_ragged_shapes(mode, path):
     gen = torch.Generator(device=dev).manual_seed(7)
     R = lambda *s: torch.rand(*s, device=dev, generator=gen) * 2 - 1
     shapes = [(1, 5, 3), (64, 64, 32), (130, 70, 45), (257, 96, 100), (200, 132, 260), (96, 28, 1000), (33, 512, 27), (300, 148, 4100)]
-    base = {"fp32_mfma": 0, "bf16x6": 10, "bf16x6_planes": 20}[path]
+    if path == "bf16x6_dma":
+        # the LDS-DMA kernel (pf_gemm3f.h) moves 16-byte chunks: K and N multiples of 4 (the PPO's padded layers); everything else --
+        # ragged M / N against the 128 x {128, 64} tiles, a ragged last k-slice, one-row problems -- is its own edge handling
+        shapes = [(1, 8, 4), (64, 64, 32), (130, 68, 44), (257, 96, 100), (200, 132, 260), (96, 28, 1000), (33, 512, 28), (300, 148, 4100), (385, 260, 36)]
+    base = {"fp32_mfma": 0, "bf16x6": 10, "bf16x6_planes": 20, "bf16x6_dma": 30}[path]
     worst = 0.0
     for (M, N, K) in shapes:
-        for tile in ((0, 1, 2, -1) if path == "fp32_mfma" else (0, 1, 2, 3, -1)):
+        for tile in ((0, 1, 2, -1) if path == "fp32_mfma" else (0, 1, -1) if path == "bf16x6_dma" else (0, 1, 2, 3, -1)):
             for splits in ((1, 7, 64) if mode == 2 else (0,)):
                 if mode == 0: A, B = R(M, K), R(N, K)
                 elif mode == 1: A, B = R(M, K), R(K, N)
@@ -227,6 +231,7 @@ def test_gemm_kernel_family_on_ragged_shapes(mode, path):
                     cs = A64.sum(0)
                     assert float((out[M * N:].double() - cs).abs().max()) <= 2e-5 * max(1.0, float(cs.abs().max())) * max(1.0, K / 64) ** 0.5
     print(f"[gemm {path} mode {mode}] worst error / float32 dot-product bound: {worst:.3f}")
+    common.record_parity(f"test_gemm_kernel_family_on_ragged_shapes[{path},mode{mode}]", worst_error_over_float32_bound=worst)
 
 
 def test_two_rank_shards_match_one_full_batch_handle():

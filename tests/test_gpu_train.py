@@ -38,6 +38,7 @@ def test_env_class_matches_oracle_and_protocol(task):
     assert bytes(sim.L) == bytes(env._L)
     rs = np.random.RandomState(0)
     cset = env.bind_contact_set()
+    mismatched = 0
     for t in range(5):
         torch.cuda.synchronize()
         sim.state[:] = env._state.cpu().numpy()
@@ -49,7 +50,8 @@ def test_env_class_matches_oracle_and_protocol(task):
         torch.cuda.synchronize()
         # strict 1e-4 wherever the kernel took the oracle's discrete decisions (reset, contact / joint-limit sets, cells)
         same = (d.cpu().numpy() == sim.reset.astype(bool)) & (cset.cpu().numpy().view(np.uint64) == sim.contact_set).all(axis=(1, 2))
-        assert same.mean() > 0.95
+        mismatched += int((~same).sum())
+        assert same.mean() >= 62 / 64                   # measured: 0 mismatched env-steps of 320 on both tasks
         assert np.abs(o.cpu().numpy()[same] - sim.obs[same]).max() <= 1e-4
         assert np.abs(r.cpu().numpy()[same] - sim.rew[same]).max() <= 1e-4
         assert d.dtype == torch.bool and extras["time_outs"].dtype == torch.bool
@@ -69,6 +71,7 @@ def test_env_class_matches_oracle_and_protocol(task):
             assert int(keep.sum()) > 32
             np.testing.assert_allclose(env.measured_heights.cpu().numpy()[keep], sim.heights[keep], atol=1e-6)
         assert ("terrain_level" in ep) == rough
+    common.record_parity(f"test_env_class_matches_oracle_and_protocol[{task}]", env_steps=5 * n, flipped=mismatched, flipped_frac=mismatched / (5 * n))
     # live views: scripts write commands / read dof state like on the reference's wrapped tensors
     env.commands[0, 0] = 0.7
     assert abs(env._state[0, env._L.commands].item() - 0.7) < 1e-7
