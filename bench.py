@@ -31,17 +31,19 @@ STEP_BYTES_PER_ENV = 2072      # algorithmic bytes per env-ste
 PPO_MFLOP_PER_ENV_STEP = 13.4  # 0.84 rollout + 12.5 update
 # HBM bytes per step-kernel launch come from the committed rocprofv3 PMC summary of THIS kernel (tools/pmc_traffic.py
 # writes it from separate --pmc passes, with the guide's gfx950 corrections); used only when kernel, task and env count match.
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r2_step_kernel_hbm_pmc.json")
+TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", f) for f in
+                    ("r3_step_kernel_hbm_pmc.json", "r3_step_kernel_hbm_pmc_anymal_c_rough.json", "r2_step_kernel_hbm_pmc.json")]
 
 
 def step_traffic(kernel_prefix, task, num_envs):
-    try:
-        with open(TRAFFIC_PROFILE) as f:
-            p = json.load(f)
-        if kernel_prefix in p["kernel"].replace(" ", "") and p["task"] == task and int(p["num_envs"]) == num_envs:
-            return float(p["traffic_bytes_per_launch"]), os.path.relpath(TRAFFIC_PROFILE, ROOT)
-    except (OSError, KeyError, ValueError):
-        pass
+    for path in TRAFFIC_PROFILES:      # newest first; a file is used only for the kernel instance, task and env count it was measured on
+        try:
+            with open(path) as f:
+                p = json.load(f)
+            if kernel_prefix in p["kernel"].replace(" ", "") and p["task"] == task and int(p["num_envs"]) == num_envs:
+                return float(p["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
     return None, None
 
 
