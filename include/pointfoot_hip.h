@@ -375,6 +375,15 @@ int ppo_normalize_advantages(PpoAlg* alg, void* stream);
 int ppo_begin_update(PpoAlg* alg, void* stream);
 /* PPO.update, one minibatch: gather, forward, KL + adaptive LR, losses, backward into d_grads. */
 int ppo_minibatch_backward(PpoAlg* alg, int32_t minibatch_index, void* stream);
+/* The same minibatch in two parts, for the multi-GPU path (no counterpart in the reference: rsl_rl is single-process, the
+ * reference's only hook is the dead --horovod flag, legged_gym/utils/helpers.py:162).  part 0: forward, losses, and every
+ * gradient except the two input layers' -- afterwards the EARLY range of d_grads is final; part 1: the rest -- afterwards the
+ * LATE range is.  The host starts the all-reduce of a range as soon as its part has been issued, so the first (90 % of the
+ * bytes) runs under the kernels of part 1, and waits for both only before ppo_minibatch_apply.  ppo_grad_groups writes
+ * {early_offset, early_length, late_offset, late_length} in floats (the early range includes the 4-float KL tail behind the
+ * parameters); returns 0, -1 on a bad config.  Needs the paired execution mode (actor and critic of equal depth). */
+int ppo_minibatch_backward_part(PpoAlg* alg, int32_t minibatch_index, int32_t part, void* stream);
+int32_t ppo_grad_groups(const PpoConfig* cfg, int64_t* ranges4);
 /* grad-norm clip (over the possibly all-reduced d_grads, divided by world_size) + Adam step */
 int ppo_minibatch_apply(PpoAlg* alg, void* stream);
 

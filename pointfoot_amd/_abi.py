@@ -200,6 +200,10 @@ def _bind_ppo(lib):
     lib.ppo_minibatch_backward.argtypes = [vp, i32, vp]
     lib.ppo_begin_update.argtypes = [vp, vp]
     lib.ppo_minibatch_apply.argtypes = [vp, vp]
+    lib.ppo_minibatch_backward_part.argtypes = [vp, i32, i32, vp]
+    lib.ppo_minibatch_backward_part.restype = i32
+    lib.ppo_grad_groups.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.ppo_grad_groups.restype = i32
     for fn in ("ppo_bind_buffers", "ppo_act", "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns",
                "ppo_normalize_advantages", "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_apply"):
         getattr(lib, fn).restype = i32
@@ -216,4 +220,4 @@ EXPORTED_SYMBOLS = [
     "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations",
     "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act",
     "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",
-    "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_apply"]
+    "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_backward_part", "ppo_grad_groups", "ppo_minibatch_apply"]

@@ -835,7 +835,7 @@ struct PpoAlg {
   PpoConfig cfg;
   PpoBuffers b;
   Net actor, critic;
-  size_t std_off = 0, nparams = 0;
+  size_t std_off = 0, nparams = 0, early_off = 0;     // early_off: first float of the EARLY gradient group (see ppo_plan)
   int device = 0;
   bool bound = false;
   int batch = 0;           // minibatch rows
@@ -857,9 +857,10 @@ struct PpoAlg {
   int max_rows = 0, max_width = 0, splits = 0;
 };
 
-static void net_layout(Net& n, const int* dims, int nl, size_t& off) {
+// layers [lo, hi) of one network into the flat buffer
+static void net_layout(Net& n, const int* dims, int nl, size_t& off, int lo, int hi) {
   n.nl = nl;
-  for (int i = 0; i < nl; ++i) {
+  for (int i = lo; i < hi; ++i) {
     n.l[i].in = dims[i]; n.l[i].out = dims[i + 1];
     // every tensor starts on a 16-byte boundary: the GEMMs read weight rows with dwordx4 loads
     off = (off + 3) & ~(size_t)3; n.l[i].w = off; off += (size_t)dims[i] * dims[i + 1];
@@ -892,9 +893,17 @@ static int ppo_check_cfg(const PpoConfig* c) {
 
 static void ppo_plan(PpoAlg* a) {
   const PpoConfig& c = a->cfg;
+  // Flat parameter / gradient layout, in the order the backward pass FINISHES gradients, last first: the input layers of
+  // both networks (their gradients come last: the LATE all-reduce group), then every other layer, the action std and -- in the
+  // gradient buffer -- the 4-float KL tail (the EARLY group, complete before the last two GEMM launches of a backward pass).
+  // Each group is one contiguous range (ppo_grad_groups), so the multi-GPU path needs two all-reduce calls per minibatch.
   size_t off = 0;
-  net_layout(a->actor, c.actor_dims, c.n_actor_layers, off);
-  net_layout(a->critic, c.critic_dims, c.n_critic_layers, off);
+  net_layout(a->actor, c.actor_dims, c.n_actor_layers, off, 0, 1);
+  net_layout(a->critic, c.critic_dims, c.n_critic_layers, off, 0, 1);
+  off = (off + 3) & ~(size_t)3;
+  a->early_off = off;
+  net_layout(a->actor, c.actor_dims, c.n_actor_layers, off, 1, c.n_actor_layers);
+  net_layout(a->critic, c.critic_dims, c.n_critic_layers, off, 1, c.n_critic_layers);
   off = (off + 3) & ~(size_t)3;
   a->std_off = off; off += c.num_actions;
   a->nparams = (off + 3) & ~(size_t)3;
@@ -1108,7 +1117,14 @@ static void mlp_forward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M,
     ina = ws + a->w_ha[i]; inc = ws + a->w_hc[i];
   }
 }
-static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s, int ldxa = 0, int ldxc = 0, const LossFinish* lf = nullptr) {
+// part: -1 = the whole pass with ONE slab-reduction launch at its end (single GPU).  0 / 1 = the pass in two parts for the
+// multi-GPU path, each ending with the reduction of the gradients it has finished, so that the all-reduce of the first
+// group runs under the kernels of the second (ppo_minibatch_backward_part):
+//   part 0: data gradients down to g_1, weight gradients of every layer but the input layer (heads included) -> EARLY group
+//           [actor / critic layers >= 1, std, KL tail]; the loss scalars are finished here;
+//   part 1: data gradient into layer 0's output, the input layers' weight gradients -> LATE group [actor L0, critic L0].
+// The flat parameter / gradient buffer is laid out group by group (ppo_plan), so each group is ONE contiguous range.
+static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s, int ldxa = 0, int ldxc = 0, const LossFinish* lf = nullptr, int part = -1) {
   const int ldx[2] = {ldxa, ldxc};
   float* ws = a->b.d_workspace; const float* P = a->b.d_params; float* G = a->b.d_grads;
   const Net* net[2] = {&a->actor, &a->critic};
@@ -1116,27 +1132,23 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
   const float* X[2] = {Xa, Xc};
   const int last = a->actor.nl - 1;
   auto g_of = [&](int set, int i) { return ws + a->w_g[set][i]; };
-  ReduceJobs js; js.n = 0; js.lf = lf ? *lf : LossFinish{};
-  {   // head gradient slabs written by k_heads
-    const int nblk = (M + HEAD_ROWS - 1) / HEAD_ROWS;
-    for (int k = 0; k < 2; ++k) { const Layer& L = net[k]->l[last]; js.j[js.n++] = reduce_plan(L.out * L.in + L.out, nblk, ws + a->w_slabl[k][last], G + L.w); }
-  }
-  for (int i = last - 1; i >= 0; --i) {
-    if (i > 0) {      // dZ_{i-1} = (g_i W_i) * ELU'(h_{i-1})
-      GemmArgs g[2];
-      for (int k = 0; k < 2; ++k) {
-        const Layer& L = net[k]->l[i];
-        g[k] = GemmArgs{};
-        g[k].A = g_of(k, i); g[k].B = P + L.w; g[k].C = g_of(k, i - 1); g[k].M = M; g[k].N = L.in; g[k].K = L.out;
-        g[k].lda = L.out; g[k].ldb = L.in; g[k].ldc = L.in; g[k].H = ws + w_h[k][i - 1]; g[k].ldh = L.in;
-      }
-      if (a->split3) {      // B = W^T planes, k (= out) contiguous
-        use_planes(a, g[0], 0, i, true); use_planes(a, g[1], 1, i, true);
-        if (a->dma && pf_gemm3f_ok<GEMM_EPI_MUL_DELU>(g[1]) && pf_gemm3f_ok<GEMM_EPI_MUL_DELU>(g[0])) pf_gemm3f_launch2<GEMM_EPI_MUL_DELU>(g[1], g[0], s);
-        else pf_gemm3_launch2<true, true, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
-      }
-      else pf_gemm_auto2<true, false, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
+  ReduceJobs js; js.n = 0; js.lf = LossFinish{};
+  auto bwd_x = [&](int i) {      // dZ_{i-1} = (g_i W_i) * ELU'(h_{i-1})
+    GemmArgs g[2];
+    for (int k = 0; k < 2; ++k) {
+      const Layer& L = net[k]->l[i];
+      g[k] = GemmArgs{};
+      g[k].A = g_of(k, i); g[k].B = P + L.w; g[k].C = g_of(k, i - 1); g[k].M = M; g[k].N = L.in; g[k].K = L.out;
+      g[k].lda = L.out; g[k].ldb = L.in; g[k].ldc = L.in; g[k].H = ws + w_h[k][i - 1]; g[k].ldh = L.in;
     }
+    if (a->split3) {      // B = W^T planes, k (= out) contiguous
+      use_planes(a, g[0], 0, i, true); use_planes(a, g[1], 1, i, true);
+      if (a->dma && pf_gemm3f_ok<GEMM_EPI_MUL_DELU>(g[1]) && pf_gemm3f_ok<GEMM_EPI_MUL_DELU>(g[0])) pf_gemm3f_launch2<GEMM_EPI_MUL_DELU>(g[1], g[0], s);
+      else pf_gemm3_launch2<true, true, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
+    }
+    else pf_gemm_auto2<true, false, GEMM_EPI_MUL_DELU>(g[1], 0, g[0], 0, s);
+  };
+  auto bwd_w = [&](int i) {
     // dW_i, db_i as split-K slabs, then the deterministic slab reduce straight into the flat gradient
     GemmArgs g[2]; int S[2], tiles3[2] = {0, 0}, want[2]; ReduceJob j[2];
     // the two networks' layer-i gradients have the same shape except at the input layer (27 vs 148 columns): both go out in
@@ -1174,8 +1186,26 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
       }
     } else pf_gemm_launch2<false, false, GEMM_EPI_NONE, true>(g[1], S[1], g[0], S[0], s);
     js.j[js.n++] = j[1]; js.j[js.n++] = j[0];
+  };
+  auto head_jobs = [&]() {      // head gradient slabs written by k_heads; the loss scalars ride in the same launch
+    const int nblk = (M + HEAD_ROWS - 1) / HEAD_ROWS;
+    for (int k = 0; k < 2; ++k) { const Layer& L = net[k]->l[last]; js.j[js.n++] = reduce_plan(L.out * L.in + L.out, nblk, ws + a->w_slabl[k][last], G + L.w); }
+    if (lf) js.lf = *lf;
+  };
+  if (part < 0) {
+    head_jobs();
+    for (int i = last - 1; i >= 0; --i) { if (i > 0) bwd_x(i); bwd_w(i); }
+    reduce_slabs_n(js, s);      // every layer has its own slabs: one reduction launch for the whole pass
+  } else if (part == 0) {
+    head_jobs();
+    for (int i = last - 1; i >= 2; --i) { bwd_x(i); bwd_w(i); }
+    if (last - 1 >= 1) bwd_w(1);      // g_1 exists (from bwd_x(2), or from k_heads when there are two hidden layers)
+    reduce_slabs_n(js, s);
+  } else {
+    if (last - 1 >= 1) bwd_x(1);
+    bwd_w(0);
+    reduce_slabs_n(js, s);
   }
-  reduce_slabs_n(js, s);      // every layer has its own slabs: one reduction launch for the whole pass
 }
 
 // The actor and the critic are independent networks: run the critic on a second stream so one network's launch tails,
@@ -1469,15 +1499,24 @@ int ppo_begin_update(PpoAlg* a, void* stream) {
   return 0;
 }
 
-int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
+}  // extern "C"
+
+static int minibatch_backward(PpoAlg* a, int32_t mb, void* stream, int part) {
   if (!a || !a->bound) { pf_set_error("ppo_minibatch_backward: buffers not bound"); return 1; }
   if (ppo_wrong_device(a)) return 1;
   const PpoConfig& c = a->cfg;
   if (mb < 0 || mb >= c.num_mini_batches) { pf_set_error("ppo_minibatch_backward: minibatch index out of range"); return 1; }
+  if (part >= 0 && !(a->fused_heads && a->paired)) { pf_set_error("ppo_minibatch_backward_part: needs the paired execution mode (equal depth, fused heads)"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   float* ws = a->b.d_workspace;
   const int B = a->batch, A = c.num_actions, O = c.num_obs, P = c.num_critic_obs;
   const int* perm = a->b.d_perm + (size_t)mb * B;
+  if (part == 1) {      // second half of a pass begun with part 0: the minibatch arrays and activations are in place
+    const size_t o_xa = a->permuted ? a->w_perm[0] + (size_t)mb * B * a->ld_xa : a->w_xa, o_xc = a->permuted ? a->w_perm[1] + (size_t)mb * B * a->ld_xc : a->w_xc;
+    mlp_backward_pair(a, ws + o_xa, ws + o_xc, B, s, a->ld_xa, a->ld_xc, nullptr, 1);
+    PPO_HIP_OK(hipGetLastError());
+    return 0;
+  }
   split_weights(a, s);
   // minibatch arrays: slices of the permuted storage (ppo_begin_update) or, without it, gathered now
   size_t mbo[9];
@@ -1511,7 +1550,7 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
                        ws + (a->paired ? a->w_slabl[0][a->actor.nl - 1] : a->w_slabs[0]), ws + (a->paired ? a->w_slabl[1][a->critic.nl - 1] : a->w_slabs[1]),
                        ws + a->w_partial);
     const LossFinish lf{nblk, A, B, c.entropy_coef, ws + a->w_partial, stdp, a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars};
-    if (a->paired) mlp_backward_pair(a, ws + o_xa, ws + o_xc, B, s, a->ld_xa, a->ld_xc, &lf);      // finished inside the slab reduction launch
+    if (a->paired) mlp_backward_pair(a, ws + o_xa, ws + o_xc, B, s, a->ld_xa, a->ld_xc, &lf, part);      // finished inside the slab reduction launch
     else {
       hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, lf);
       s2 = ppo_fork(a, s);
@@ -1533,6 +1572,23 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) {
   }
   ppo_join(a, s, s2);
   PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" {
+
+int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) { return minibatch_backward(a, mb, stream, -1); }
+
+int ppo_minibatch_backward_part(PpoAlg* a, int32_t mb, int32_t part, void* stream) {
+  if (part != 0 && part != 1) { pf_set_error("ppo_minibatch_backward_part: part must be 0 or 1"); return 1; }
+  return minibatch_backward(a, mb, stream, part);
+}
+
+int32_t ppo_grad_groups(const PpoConfig* cfg, int64_t* ranges) {
+  if (ppo_check_cfg(cfg) || !ranges) return -1;
+  PpoAlg a; a.cfg = *cfg; ppo_plan(&a);
+  ranges[0] = (int64_t)a.early_off; ranges[1] = (int64_t)(a.nparams + 4 - a.early_off);      // EARLY: layers >= 1, std, KL tail
+  ranges[2] = 0; ranges[3] = (int64_t)a.early_off;                                          // LATE: the two input layers
   return 0;
 }
 

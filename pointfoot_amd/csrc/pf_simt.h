@@ -30,7 +30,17 @@
 #define PF_DEV static __device__ __forceinline__
 // PF_W = lanes per robot: a constexpr in scope at every use (PfKernel::PF_W).  64: one robot per wavefront; 32: two robots
 // per wavefront, one per half -- uniform sections and loops over <= 32 items then cost one instruction for two robots.
-#define PF_LANE_ID ((int)threadIdx.x & (PF_W - 1))
+// PF_OPAQUE_LANE (a constexpr in scope at every use, PfKernel::PF_OPAQUE_LANE): the lane id is re-materialised behind an empty
+// volatile asm at every use, so nothing derived from it (LDS addresses, lane == k masks) can be hoisted out of the substep loop
+// and kept alive across it.  The quadruped kernel hoisted so much of that above its loop that 41 VGPRs spilled to scratch
+// (10 KB of scratch writes per robot and step: two thirds of the kernel's HBM write traffic).
+template <bool OPQ>
+PF_DEV int pf_thread_id() {
+  int t = (int)threadIdx.x;
+  if constexpr (OPQ) asm volatile("" : "+v"(t));
+  return t;
+}
+#define PF_LANE_ID (pf_thread_id<PF_OPAQUE_LANE>() & (PF_W - 1))
 #define PF_LANES(i, n) for (int i = PF_LANE_ID; i < (n); i += PF_W)
 // One wavefront (or half of one) per robot, possibly several wavefronts per workgroup that share only read-only data: a
 // "barrier" has to order just the wave's own LDS traffic.  The hardware executes a wave's LDS instructions in order, which

@@ -200,6 +200,7 @@ template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH
 struct PfKernel {
   static constexpr int PF_W = 64 / RPW;         // lanes per robot (pf_simt.h)
   static constexpr bool LR = KIND == PF_KIND_LEGGED_ROBOT;      // LeggedRobot / Anymal semantics (legged_robot.py)
+  static constexpr bool PF_OPAQUE_LANE = LR;                    // pf_simt.h: no hoisting of lane-derived values (register pressure)
   static constexpr int REC_MAX = LR ? 704 : PF_REC_MAX;
   static constexpr int NV = 6 + ND;
   static constexpr int NVP = NV | 1;          // odd row stride: per-lane rows hit distinct LDS banks

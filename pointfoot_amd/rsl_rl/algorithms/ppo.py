@@ -3,6 +3,7 @@ behind the ppo_* C ABI.  Multi-GPU: env-sharded data parallelism — every rank 
 minibatch, the flat gradient (+ the KL sum in its tail) is all-reduced over RCCL before the fused clip + Adam step,
 so all ranks take identical parameter and learning-rate steps."""
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -111,6 +112,13 @@ class PPO:
         self._bufs = b
         _abi.check(lib.ppo_bind_buffers(self._h, C.byref(b)), lib)
         self._actions = torch.zeros(num_envs, c.num_actions, device=dev)
+        # multi-GPU: the gradient buffer as two contiguous ranges in the order the backward pass finishes them
+        rng = (C.c_int64 * 4)()
+        self._grad_groups = None
+        if lib.ppo_grad_groups(C.byref(c), rng) == 0 and c.n_actor_layers == c.n_critic_layers:
+            e0, en, l0, ln = (int(v) for v in rng)
+            assert l0 == 0 and e0 == ln and e0 + en == P + 4
+            self._grad_groups = (self.grads[e0:e0 + en], self.grads[l0:l0 + ln])
 
     def test_mode(self):
         self.actor_critic.eval()
@@ -154,10 +162,25 @@ class PPO:
         self.perm.copy_(torch.randperm(n, device=self.device).to(torch.int32))
         self.scalars[SC_VLOSS:SC_SLOSS + 1] = 0.0
         _abi.check(lib.ppo_begin_update(self._h, self._stream()), lib)      # storage into permutation order, once for all epochs
+        overlap = self.world_size > 1 and self._grad_groups is not None and os.environ.get("PF_PPO_OVERLAP_ALLREDUCE", "1") != "0"
         for _epoch in range(self.num_learning_epochs):
             for mb in range(self.num_mini_batches):
-                _abi.check(lib.ppo_minibatch_backward(self._h, mb, self._stream()), lib)
-                dp.allreduce_grads(self.grads)           # RCCL over xGMI: 1.68 MB for pointfoot_rough
+                if overlap:
+                    # the backward pass in two parts: the all-reduce of the gradients finished by the first (every layer but the
+                    # two input layers, std, the KL tail: 90 % of the 1.68 MB for pointfoot_rough) runs over xGMI while the last
+                    # data-gradient GEMM and the input layers' weight gradients are still computing; the host waits for nothing,
+                    # the stream waits for both collectives just before the optimiser step
+                    early, late = self._grad_groups
+                    _abi.check(lib.ppo_minibatch_backward_part(self._h, mb, 0, self._stream()), lib)
+                    w0 = dp.allreduce_async(early)
+                    _abi.check(lib.ppo_minibatch_backward_part(self._h, mb, 1, self._stream()), lib)
+                    w1 = dp.allreduce_async(late)
+                    for w in (w0, w1):
+                        if w is not None:
+                            w.wait()
+                else:
+                    _abi.check(lib.ppo_minibatch_backward(self._h, mb, self._stream()), lib)
+                    dp.allreduce_grads(self.grads)           # RCCL over xGMI: 1.68 MB for pointfoot_rough
                 _abi.check(lib.ppo_minibatch_apply(self._h, self._stream()), lib)
         num_updates = self.num_learning_epochs * self.num_mini_batches
         st.clear()

@@ -38,6 +38,16 @@ def allreduce_grads(flat_with_tail):
     return flat_with_tail
 
 
+def allreduce_async(t):
+    """start the sum over ranks of one contiguous gradient range; returns the work handle (None on one rank).  On the nccl
+    (= RCCL) backend the collective is ordered after the kernels already issued on the current stream and runs on the process
+    group's own stream -- beside whatever is issued next; `wait()` makes the current stream wait for it (no host sync)."""
+    rank, ws = world()
+    if ws > 1:
+        return dist.all_reduce(t, async_op=True)
+    return None
+
+
 def allreduce_adv_stats(stats3):
     rank, ws = world()
     if ws > 1:

@@ -331,3 +331,38 @@ def test_minibatch_size_is_floored_like_rsl_rl():
     g_ref, g = ref.flat_grad(alg.param_offsets, alg.num_params), alg.grads[:alg.num_params]
     assert (g - g_ref).abs().max().item() <= 3e-4 * g_ref.abs().max().item() + 1e-7
     assert alg.grads[alg.num_params + 1].item() == 8.0          # sample count in the KL tail
+
+
+@pytest.mark.parametrize("hidden", [[512, 256, 128], [64, 32]])
+def test_backward_in_two_parts_equals_the_whole_pass(hidden):
+    """Multi-GPU path: ppo_minibatch_backward_part(0) + (1) -- the pass cut where the EARLY gradient range is
+    final, so that its all-reduce can run under the rest -- must leave bit-identical gradients to ppo_minibatch_backward,
+    the two ranges of ppo_grad_groups must tile the buffer, and after part 0 the early range must already hold its final
+    values while the late range (the two input layers) is still untouched."""
+    N, T, O, P, A = 128, 8, 27, 148, 6
+    alg, ref = make(N, T, O, P, A, hidden, seed=3)
+    gen = torch.Generator(device="cuda:0").manual_seed(5)
+    fill_rollout(alg, ref, N, T, O, P, A, gen)
+    lib, h, s = alg._lib, alg._h, alg._stream()
+    early, late = alg._grad_groups
+    assert early.numel() + late.numel() == alg.grads.numel() and late.data_ptr() == alg.grads.data_ptr()
+    assert early.data_ptr() == alg.grads.data_ptr() + 4 * late.numel()
+    # the late range is exactly the two input layers (W, b of actor layer 0 and critic layer 0, 16-byte padded)
+    assert late.numel() >= hidden[0] * (O + 1) + hidden[0] * (P + 1) and late.numel() <= hidden[0] * (O + 1) + hidden[0] * (P + 1) + 16
+    alg.perm.copy_(torch.randperm(N * T, device="cuda:0", generator=gen).to(torch.int32))
+    common._abi.check(lib.ppo_begin_update(h, s), lib)
+    for mb in range(alg.num_mini_batches):
+        SENT = 12345.0      # (the padding floats between tensors are never written: they keep the sentinel on both sides)
+        alg.grads.fill_(SENT)
+        common._abi.check(lib.ppo_minibatch_backward(h, mb, s), lib)
+        whole = alg.grads.clone()
+        assert torch.isfinite(whole).all() and int((whole != SENT).sum()) >= alg.num_params - 64
+        alg.grads.fill_(SENT)
+        common._abi.check(lib.ppo_minibatch_backward_part(h, mb, 0, s), lib)
+        torch.cuda.synchronize()
+        assert torch.equal(early, whole[late.numel():]), "early range not final after part 0"
+        assert bool((late == SENT).all()), "part 0 wrote into the late range"
+        common._abi.check(lib.ppo_minibatch_backward_part(h, mb, 1, s), lib)
+        torch.cuda.synchronize()
+        assert torch.equal(alg.grads, whole)
+    assert lib.ppo_minibatch_backward_part(h, 0, 2, s) != 0
