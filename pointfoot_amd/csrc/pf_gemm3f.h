@@ -273,6 +273,8 @@ static inline bool pf_gemm3f_ok(const GemmArgs& g) {
 // 128 x 128 tiles of everything in the launch: the actor's and the critic's layer share one) or N has a 64-wide remainder.
 // (Measured and dropped, profiles/r3_gemm_dma_ablation.txt: BK = 16 stages for four workgroups per CU; 192-row tiles on
 // v_mfma_f32_16x16x32_bf16.)
+// (Also measured and dropped: 64-deep k-slices for the rollout's 4096-row launches -- half as many DMA / barrier round trips per
+// block, but 21.5 vs 18.1 us on 4096 x 256 x 512: the first stage takes twice as long to land and one workgroup per CU hides nothing.)
 static inline int pf_gemm3f_pick(int N, long tiles128) { return ((N % 128 == 0 && tiles128 >= 512) || N > 512) ? 0 : 1; }
 static inline long pf_gemm3f_tiles128(const GemmArgs& g) { return (long)((g.M + 127) / 128) * ((g.N + 127) / 128); }
 template <int BN>
