@@ -287,6 +287,9 @@ int pf_reset_idx(PfEnv* env, const uint8_t* d_mask, int64_t step_counter, const 
 
 /* replaces: compute_observations() re-run by update_cmd (point_foot.py:123-129) */
 int pf_compute_observations(PfEnv* env, int64_t step_counter, const PfInject* inject, void* stream);
+/* The height scan alone (reference: the `measured_heights` attribute, point_foot.py:213 / :1048-1075): fills
+ * PfBuffers.d_measured_heights for the current state and writes nothing else -- no observation, reward or state buffer. */
+int pf_measure_heights(PfEnv* env, void* stream);
 
 /* ------------------------------------------------------------------------------------------- PPO
  * replaces rsl_rl v1.0.2 (un-vendored dependency; setup.py:13): OnPolicyRunner.learn's inner calls

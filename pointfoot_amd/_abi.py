@@ -166,6 +166,8 @@ def load():
     lib.pf_destroy.argtypes = [vp]
     lib.pf_bind_buffers.argtypes = [vp, C.POINTER(PfBuffers)]
     lib.pf_update_config.argtypes = [vp, C.POINTER(PfConfig)]
+    lib.pf_measure_heights.argtypes = [vp, vp]
+    lib.pf_measure_heights.restype = i32
     lib.pf_set_reset_stats.argtypes = [vp, vp]
     lib.pf_set_reset_stats.restype = i32
     lib.pf_set_reset_stats_next.argtypes = [vp, vp]
@@ -216,7 +218,7 @@ def check(rc, lib=None):
 
 
 EXPORTED_SYMBOLS = [
-    "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers", "pf_set_reset_stats", "pf_set_reset_stats_next",
+    "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers", "pf_set_reset_stats", "pf_set_reset_stats_next", "pf_measure_heights",
     "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations",
     "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act",
     "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",

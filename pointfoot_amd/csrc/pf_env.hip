@@ -226,7 +226,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   g.actions = d_actions; g.step_counter = step_counter; g.mode = mode; g.stamps = e->d_stamps; g.reset_mask = d_mask;
   hipStream_t s = (hipStream_t)stream;
   g.stats_next = nullptr;
-  if (e->bufs.d_reset_stats && mode != 2) {
+  if (e->bufs.d_reset_stats && mode < 2) {
     // cleared by the previous launch when the caller announced it with pf_set_reset_stats_next; otherwise clear it now
     if (e->stats_cleared != e->bufs.d_reset_stats) PF_HIP_OK(hipMemsetAsync(e->bufs.d_reset_stats, 0, sizeof(float) * PF_STATS_FLOATS, s));
     g.stats_next = (e->stats_next && e->stats_next != e->bufs.d_reset_stats) ? e->stats_next : nullptr;
@@ -262,6 +262,10 @@ int pf_reset_idx(PfEnv* e, const uint8_t* d_mask, int64_t step_counter, const Pf
 }
 int pf_compute_observations(PfEnv* e, int64_t step_counter, const PfInject* inject, void* stream) {
   return pf_launch(e, nullptr, step_counter, inject, stream, 2);
+}
+int pf_measure_heights(PfEnv* e, void* stream) {
+  if (e && e->bound && !e->bufs.d_measured_heights) { pf_set_error("pf_measure_heights: d_measured_heights is not bound"); return 1; }
+  return pf_launch(e, nullptr, 0, nullptr, stream, 3);
 }
 
 }  // extern "C"

@@ -190,7 +190,7 @@ struct PfStepArgs {
   PfInject inj;
   const float* actions;
   long long step_counter;
-  int mode;               // 0 = step, 1 = reset_idx(all), 2 = compute_observations only
+  int mode;               // 0 = step, 1 = reset_idx(all), 2 = compute_observations only, 3 = the height scan only (fills d_measured_heights)
   unsigned* stamps;       // diagnostic build only, else NULL
   float* stats_next;      // next step's statistics slot, cleared by this launch (NULL: the host clears slots itself)
   const uint8_t* reset_mask;   // mode 1 only: envs to reset (NULL: all) -- reset_idx(env_ids), point_foot.py:249
@@ -1396,10 +1396,10 @@ struct PfKernel {
       PF_LANES(i, L.rec_floats) grow[i] = S[i];
       return;
     }
-    if (g.mode == 2) {      // compute_observations() (:123-129, :320-326): measured_heights are taken afresh (:213 / :324)
+    if (g.mode == 2 || g.mode == 3) {      // compute_observations() (:123-129, :320-326): measured_heights are taken afresh (:213 / :324)
       if (c.measure_heights) (void)height_scan(sh, c, B, env);
       PF_SYNC();
-      observations(sh, c, L, B, inj, env, g.step_counter);
+      if (g.mode == 2) observations(sh, c, L, B, inj, env, g.step_counter);      // mode 3: a read of the measured_heights attribute, nothing else is written
       return;
     }
     PF_LANES(k, c.num_actions) S[LC::actions + k] = pf_clip(g.actions[(size_t)env * c.num_actions + k], -c.clip_actions, c.clip_actions);   // :176-177

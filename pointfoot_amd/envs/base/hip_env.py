@@ -158,7 +158,9 @@ class HipEnv:
             self._measured_heights = torch.zeros(self.num_envs, H, device=self.device, dtype=torch.float)
             self._bufs.d_measured_heights = _native.ptr(self._measured_heights)
             _abi.check(self._lib.pf_bind_buffers(self._h, C.byref(self._bufs)), self._lib)
-            self.compute_observations()       # fills it for the current state
+            # fill it for the current state with the height scan alone: reading the attribute must not rewrite obs_buf /
+            # privileged_obs_buf mid-rollout (a caller may have injected draws or changed commands since the last step)
+            _abi.check(self._lib.pf_measure_heights(self._h, self._stream()), self._lib)
         return self._measured_heights
 
     @property

@@ -62,8 +62,11 @@ def test_env_class_matches_oracle_and_protocol(task):
         if rough and t == 2:
             # `measured_heights` is materialised on first access (the kernel keeps the scan in LDS otherwise) ...
             assert env._measured_heights is None
+            o_before, p_before, r_before = o.clone(), p.clone(), r.clone()
             mh = env.measured_heights
             torch.cuda.synchronize()
+            # ... by the height scan alone: the attribute read leaves observations / rewards as the step wrote them
+            assert torch.equal(o, o_before) and torch.equal(p, p_before) and torch.equal(r, r_before)
             keep = ~sim.reset.astype(bool) & same
             np.testing.assert_allclose(mh.cpu().numpy()[keep], sim.heights[keep], atol=1e-6)
         if rough and t == 3:      # ... and is then written by every step
