@@ -178,7 +178,18 @@ def main():
         local = 0
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group(a.backend)
+        # the collective libraries print connection banners to fd 1 from C++ (gloo: "[Gloo] Rank 0 is connected to ..."): stdout
+        # carries the one JSON line only, so fd 1 points at stderr while the process group comes up
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(a.backend)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
