@@ -176,7 +176,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.single_device:
         local = 0
-    if world > 1:
+    # PF_DP_SINGLE_RANK_COLLECTIVES=1: a process group of ONE rank with every collective of the N>1 path issued anyway (dp.collectives_on):
+    # the rehearsal of the multi-GPU code path through RCCL on a one-GPU box
+    rehearse1 = world == 1 and os.environ.get("PF_DP_SINGLE_RANK_COLLECTIVES", "0") == "1"
+    if rehearse1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    dist_on = world > 1 or rehearse1
+    if dist_on:
         torch.cuda.set_device(local)
         # the collective libraries print connection banners to fd 1 from C++ (gloo: "[Gloo] Rank 0 is connected to ..."): stdout
         # carries the one JSON line only, so fd 1 points at stderr while the process group comes up
@@ -235,7 +242,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] warm-up done ({a.warmup} iterations)", file=sys.stderr, flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -244,11 +251,11 @@ def main():
     end_mark = torch.cuda.Event(enable_timing=True)
     end_mark.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -297,7 +304,7 @@ def main():
         finally:
             del os.environ["PF_PPO_GEMM"]
     lockstep = None
-    if world > 1:
+    if dist_on:
         # every rank must hold the same policy and have taken the same learning-rate decisions: compare a checksum of the
         # flat parameter buffer (as exact integers: the float32 bit patterns summed in int64) and the LR scalar across ranks
         alg = runner.alg
@@ -341,6 +348,8 @@ def main():
                        "parallelism": f"dp{n_gpus} (env shards, RCCL gradient all-reduce)" if n_gpus > 1 else "single GPU",
                        "finite": finite},
             "ranks_in_lockstep": lockstep,
+            "collectives": ((f"{a.backend} group of ONE rank, every collective of the N>1 path issued (PF_DP_SINGLE_RANK_COLLECTIVES=1 rehearsal)" if rehearse1
+                             else f"{a.backend}, {world} ranks") if dist_on else None),
             "alt_fp32_mfma": alt,
             "roofline": {"kernel": kern + " (fused env step)", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
@@ -376,7 +385,7 @@ def main():
             except Exception as ex:      # the baseline is informational; never lose the GPU measurement over it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -224,10 +224,10 @@ class HipEnv:
         i = self._sum_names.index("tracking_lin_vel")
         stats = self._reset_stats
         pair = torch.stack([stats[i], stats[_abi.PF_MAX_REWARDS]])
-        if self.world_size > 1:
+        from pointfoot_amd.rsl_rl import dp
+        if dp.collectives_on():
             # every rank must take the same decision (the command range is one number for the whole job): sums and counts of
             # all shards, i.e. the mean one process with all the envs would see.  Once per max_episode_length steps.
-            from pointfoot_amd.rsl_rl import dp
             pair = dp.allreduce_sum(pair.clone())
         tot, cnt = (float(v) for v in pair.tolist())         # host sync, once per max_episode_length steps
         if cnt <= 0:

@@ -162,7 +162,7 @@ class PPO:
         self.perm.copy_(torch.randperm(n, device=self.device).to(torch.int32))
         self.scalars[SC_VLOSS:SC_SLOSS + 1] = 0.0
         _abi.check(lib.ppo_begin_update(self._h, self._stream()), lib)      # storage into permutation order, once for all epochs
-        overlap = self.world_size > 1 and self._grad_groups is not None and os.environ.get("PF_PPO_OVERLAP_ALLREDUCE", "1") != "0"
+        overlap = dp.collectives_on() and self._grad_groups is not None and os.environ.get("PF_PPO_OVERLAP_ALLREDUCE", "1") != "0"
         for _epoch in range(self.num_learning_epochs):
             for mb in range(self.num_mini_batches):
                 if overlap:

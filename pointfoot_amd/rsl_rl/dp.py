@@ -14,6 +14,15 @@ def world():
     return 0, 1
 
 
+def collectives_on():
+    """True when the collectives of the path have to be issued: more than one rank -- or a group of ONE rank with
+    PF_DP_SINGLE_RANK_COLLECTIVES=1, the hardware rehearsal of the N>1 code path on a one-GPU box (every all-reduce /
+    broadcast of the path then really goes through RCCL and its stream ordering; the sums are identities)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("PF_DP_SINGLE_RANK_COLLECTIVES", "0") == "1"
+
+
 def shard(num_envs_per_rank, rank=None, world_size=None):
     """global env index range owned by `rank`: [base, base + n)"""
     if rank is None or world_size is None:
@@ -24,16 +33,14 @@ def shard(num_envs_per_rank, rank=None, world_size=None):
 
 
 def sync_params(flat):
-    rank, ws = world()
-    if ws > 1:
+    if collectives_on():
         dist.broadcast(flat, src=0)
     return flat
 
 
 def allreduce_grads(flat_with_tail):
     """sum over ranks, in place; the consumer divides by world_size (ppo_minibatch_apply: gscale = 1/world_size)"""
-    rank, ws = world()
-    if ws > 1:
+    if collectives_on():
         dist.all_reduce(flat_with_tail)
     return flat_with_tail
 
@@ -42,23 +49,20 @@ def allreduce_async(t):
     """start the sum over ranks of one contiguous gradient range; returns the work handle (None on one rank).  On the nccl
     (= RCCL) backend the collective is ordered after the kernels already issued on the current stream and runs on the process
     group's own stream -- beside whatever is issued next; `wait()` makes the current stream wait for it (no host sync)."""
-    rank, ws = world()
-    if ws > 1:
+    if collectives_on():
         return dist.all_reduce(t, async_op=True)
     return None
 
 
 def allreduce_adv_stats(stats3):
-    rank, ws = world()
-    if ws > 1:
+    if collectives_on():
         dist.all_reduce(stats3)
     return stats3
 
 
 def allreduce_sum(t):
     """in-place sum over ranks of a small statistics tensor (episode sums and counts); a no-op on one rank"""
-    rank, ws = world()
-    if ws > 1:
+    if collectives_on():
         dist.all_reduce(t)
     return t
 
@@ -97,7 +101,7 @@ def reduce_episode_infos(ep_infos, device):
         for key in ep_infos[0]:
             vals = [ep[key] for ep in ep_infos if key in ep]
             v = torch.nanmean(torch.stack([torch.as_tensor(x, dtype=torch.float).reshape(()).to(device) for x in vals])).reshape(1)
-            if ws > 1:
+            if collectives_on():
                 v = torch.nan_to_num(v); dist.all_reduce(v); v = v / ws
             out[key] = float(v)
     return out

@@ -64,7 +64,7 @@ class OnPolicyRunner:
             obs, privileged_obs, rewards, dones, infos = env.step(actions)
             critic_obs = privileged_obs if privileged_obs is not None else obs
             alg.process_env_step(rewards, dones, infos)
-            if (self.log_dir is not None or self.world_size > 1) and 'episode' in infos:
+            if (self.log_dir is not None or dp.collectives_on()) and 'episode' in infos:
                 ep_infos.append(infos['episode'])
             # (episode return / length bookkeeping happens inside ppo_process_env_step, on the device)
         alg.compute_returns(critic_obs)
