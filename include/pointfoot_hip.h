@@ -38,7 +38,8 @@ extern "C" {
 #define PF_MAX_TERM 8
 #define PF_MAX_PEN 20
 #define PF_MAX_CAPS 16         /* collision capsules (pairs of equal-radius spheres on one body; a lone sphere is a capsule of length 0) */
-#define PF_MAX_PAIRS 32        /* self-collision capsule pairs */
+#define PF_MAX_PAIRS 64        /* self-collision capsule pairs (PointFoot: 16; a quadruped with 3-link legs: 54) */
+#define PF_CSET_WORDS 4        /* 64-bit words per (env, substep) of PfBuffers.d_contact_set */
 #define PF_STATS_FLOATS (PF_MAX_REWARDS + 4)
 #define PF_STAT_CAP_HITS (PF_MAX_REWARDS + 1)     /* d_reset_stats: (env, substep) pairs of this launch with more active contact candidates than the solver keeps */
 #define PF_STAT_CAP_DROPPED (PF_MAX_REWARDS + 2)  /* d_reset_stats: contact candidates dropped by that cap in this launch */
@@ -232,12 +233,13 @@ typedef struct PfBuffers {
                                   [PF_STAT_CAP_DROPPED] = contact-cap diagnostics (HIP path only); zeroed by pf_step */
   const float* d_joint_friction; /* (N, nd) Coulomb joint friction torque per DOF (update_frictions, point_foot.py:103-108:
                                   dof_props["friction"]) or NULL = none */
-  uint64_t* d_contact_set;     /* (N, decimation, 3) or NULL.  Diagnostic output for parity tests, the discrete decisions of
-                                  substep `sub`: word 0 = bit c set when contact candidate c was active (candidates: floor
-                                  contact of sphere s = s, vertical-face contact of sphere s = nsph + s, capsule pair
-                                  p = 2 nsph + p); word 1 = joint-limit rows, 2 bits per DOF (1: at the lower, 2: at the upper limit); word 2 = sum
-                                  over the kept terrain contacts of (candidate + 1) * (4 * grid cell + face): which cell of
-                                  the (piecewise, stepped) collision surface each contact was evaluated in */
+  uint64_t* d_contact_set;     /* (N, decimation, PF_CSET_WORDS) or NULL.  Diagnostic output for parity tests, the discrete decisions of
+                                  substep `sub`: word 0 = bit c set when contact candidate c < 64 was active, word 3 = the same for
+                                  candidates 64..127 (candidates: floor contact of sphere s = s, vertical-face contact of sphere
+                                  s = nsph + s, capsule pair p = 2 nsph + p); word 1 = joint-limit rows, 2 bits per DOF (1: at the
+                                  lower, 2: at the upper limit); word 2 = sum over the kept terrain contacts of
+                                  (candidate + 1) * (4 * grid cell + face): which cell of the (piecewise, stepped) collision
+                                  surface each contact was evaluated in */
 } PfBuffers;
 
 /* Optional injected inputs (parity tests).  All NULL in production. */

@@ -463,7 +463,7 @@ void physics_substep(const Ctx& x, float* S, bool apply_ext, int env, int sub, i
   struct Contact { int body, body_b; V3<R> n, t1, t2; R mu; R A[3][3]; };
   Contact cons[MAXC];
   int ncon = 0, nrows = 0;
-  uint64_t cset = 0, cells = 0;
+  uint64_t cset[2] = {0, 0}, cells = 0;      // candidates 0..63 / 64..127
   const R mu_env = (R)0.5 * ((R)S[L.friction] + (R)c.terrain_friction);
   const R rest = (R)0.5 * (R)c.terrain_restitution;
   // contact candidates in a fixed order -- floor contact of sphere s (candidate s), vertical-face contact of sphere s
@@ -499,7 +499,7 @@ void physics_substep(const Ctx& x, float* S, bool apply_ext, int env, int sub, i
       xc = c2 + (rb + (R)0.5 * dist) * n;                          // middle of the gap / overlap
     }
     if (!(dist < (R)c.contact_offset)) continue;
-    cset |= (uint64_t)1 << cand;
+    cset[cand >> 6] |= (uint64_t)1 << (cand & 63);
     if (cand < 2 * m.nsph) { const int s = cand < m.nsph ? cand : cand - m.nsph; cells += (uint64_t)(cand + 1) * (uint64_t)(4 * hit[s].cell + (cand < m.nsph ? 0 : hit[s].face)); }
     // tangent basis
     V3<R> ref = std::fabs(n.x) < (R)0.9 ? V3<R>{1, 0, 0} : V3<R>{0, 1, 0};
@@ -559,9 +559,8 @@ void physics_substep(const Ctx& x, float* S, bool apply_ext, int env, int sub, i
     lset |= (uint64_t)(side > 0 ? 1 : 2) << (2 * k);
   }
   if (x.b->d_contact_set) {
-    x.b->d_contact_set[((size_t)env * c.decimation + sub) * 3] = cset;
-    x.b->d_contact_set[((size_t)env * c.decimation + sub) * 3 + 1] = lset;
-    x.b->d_contact_set[((size_t)env * c.decimation + sub) * 3 + 2] = cells;
+    uint64_t* o = x.b->d_contact_set + ((size_t)env * c.decimation + sub) * PF_CSET_WORDS;
+    o[0] = cset[0]; o[1] = lset; o[2] = cells; o[3] = cset[1];
   }
   for (int rI = 0; rI < nrows; ++rI) {
     solve(rows[rI].J, rows[rI].MinvJ);

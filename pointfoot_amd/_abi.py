@@ -16,7 +16,8 @@ PF_MAX_HPTS = 192
 PF_MAX_TERM = 8
 PF_MAX_PEN = 20
 PF_MAX_CAPS = 16
-PF_MAX_PAIRS = 32
+PF_MAX_PAIRS = 64
+PF_CSET_WORDS = 4
 PPO_MAX_LAYERS = 4
 PF_STATS_FLOATS = PF_MAX_REWARDS + 4
 PF_STAT_CAP_HITS = PF_MAX_REWARDS + 1

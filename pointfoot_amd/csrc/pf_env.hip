@@ -31,9 +31,9 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // WPB wavefronts per workgroup (each with RPW robots) share one read-only block (model, actuator parameters) in LDS; the
 // rest of the LDS is per robot.  WAVES = waves per SIMD the register budget is sized for.  LDS comes as dynamic shared
 // memory (the quadruped workgroup of 8 robots needs ~145 KB, above the static limit).
-template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1>
+template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0)>
 __global__ __launch_bounds__(64 * WPB, WPB == 1 ? WAVES : 1) void pf_step_kernel(const PfModel* __restrict__ model, const PfConfig* __restrict__ cfg, PfStepArgs g) {
-  using K = PfKernel<NB, ND, NF, KIND, KS, RPW>;
+  using K = PfKernel<NB, ND, NF, KIND, KS, RPW, KPR>;
   extern __shared__ __attribute__((aligned(16))) unsigned char pf_lds[];
   typename K::SharedRO& ro = *reinterpret_cast<typename K::SharedRO*>(pf_lds);
   typename K::Shared* sh = reinterpret_cast<typename K::Shared*>(pf_lds + ((sizeof(typename K::SharedRO) + 15) & ~size_t(15)));
@@ -98,13 +98,15 @@ int pf_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out) {
   return 0;
 }
 
-// kernel instances built: PointFoot PF_P441A (9 bodies / 6 dofs / 2 feet) and LeggedRobot quadrupeds with 3-DOF legs and
-// separate feet (17 / 12 / 4: ANYmal-C, ANYmal-B, A1)
+// kernel instances built: 0 = PointFoot PF_P441A (9 bodies / 6 dofs / 2 feet, self-collision built in); LeggedRobot quadrupeds
+// with 3-DOF legs and separate feet (17 / 12 / 4: ANYmal-C, ANYmal-B, A1): 1 = built without self-collision (anymal_c_rough,
+// BASELINE config 5), 2 = with it (models that come with capsule pairs: anymal_c_flat)
 static int pf_instance(const PfModel* m, const PfConfig* c) {
   if (c->env_kind == PF_KIND_POINTFOOT && m->nb == 9 && m->nd == 6 && m->nfeet == 2) return 0;
-  if (c->env_kind == PF_KIND_LEGGED_ROBOT && m->nb == 17 && m->nd == 12 && m->nfeet == 4) return 1;
+  if (c->env_kind == PF_KIND_LEGGED_ROBOT && m->nb == 17 && m->nd == 12 && m->nfeet == 4) return (c->self_collisions && m->npair > 0) ? 2 : 1;
   return -1;
 }
+using PfKernelQuadSelf = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_KPAIR_QUAD>;
 static int pf_validate(const PfModel* m, const PfConfig* c) {
   int inst = pf_instance(m, c);
   if (inst < 0) {
@@ -123,15 +125,17 @@ static int pf_validate(const PfModel* m, const PfConfig* c) {
   }
   if (m->ncap < 0 || m->npair < 0 || m->ncap > PF_MAX_CAPS || m->npair > PF_MAX_PAIRS ||
       (inst == 0 && (m->ncap > PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::KC || m->npair > PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::KP)) ||
-      (inst == 1 && (c->self_collisions || m->npair > 0))) {
-    pf_set_error("pf_create: self-collision geometry outside the compiled limits (PointFoot: 8 capsules / 16 pairs; LeggedRobot: none)");
+      (inst == 1 && c->self_collisions) ||
+      (inst == 2 && (m->ncap > PfKernelQuadSelf::KC || m->npair > PfKernelQuadSelf::KP))) {
+    pf_set_error("pf_create: self-collision geometry outside the compiled limits (PointFoot: 8 capsules / 16 pairs; LeggedRobot: 16 / 56; "
+                 "self_collisions set needs capsule pairs in the model)");
     return 1;
   }
   for (int p = 0; p < m->npair; ++p)
     if (m->pair_a[p] < 0 || m->pair_a[p] >= m->ncap || m->pair_b[p] < 0 || m->pair_b[p] >= m->ncap) { pf_set_error("pf_create: capsule pair index out of range"); return 1; }
   for (int k = 0; k < m->ncap; ++k)
     if (m->cap_s0[k] < 0 || m->cap_s0[k] >= m->nsph || m->cap_s1[k] < 0 || m->cap_s1[k] >= m->nsph) { pf_set_error("pf_create: capsule sphere index out of range"); return 1; }
-  if (2 * m->nsph + m->npair > 64) { pf_set_error("pf_create: more than 64 contact candidates"); return 1; }
+  if (2 * m->nsph + m->npair > 128) { pf_set_error("pf_create: more than 128 contact candidates"); return 1; }
   if (inst == 1 && c->num_priv_obs != 0) { pf_set_error("pf_create: LeggedRobot has no privileged observations"); return 1; }
   for (int i = 1; i < m->nb; ++i)
     if (m->parent[i] < 0 || m->parent[i] >= i) { pf_set_error("pf_create: bodies must be in depth-first order"); return 1; }
@@ -146,7 +150,8 @@ PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device) {
   pf_compute_layout(model, cfg, &e->layout);
   e->instance = pf_instance(model, cfg);
   bool lay_ok = e->instance == 0 ? PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::layout_matches(e->layout)
-                                 : PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>::layout_matches(e->layout);
+              : e->instance == 1 ? PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>::layout_matches(e->layout)
+                                 : PfKernelQuadSelf::layout_matches(e->layout);
   if (!lay_ok) { pf_set_error("pf_create: record layout differs from the kernel's compile-time layout"); delete e; return nullptr; }
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&e->d_model, sizeof(PfModel)) != hipSuccess ||
       hipMalloc(&e->d_cfg, sizeof(PfConfig)) != hipSuccess ||
@@ -233,7 +238,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
     e->stats_cleared = g.stats_next;
   }
   const int N = e->cfg.num_envs;
-  // Two kernel instances.  PointFoot: two robots per wavefront (one per 32-lane half), one wavefront per workgroup.
+  // Three kernel instances (the quadruped with and without self-collision).  PointFoot: two robots per wavefront (one per 32-lane half), one wavefront per workgroup.
   // LeggedRobot: one robot per wavefront, 8 wavefronts per workgroup sharing the read-only LDS block.  (Measured and
   // dropped: one or four PointFoot robots per wave, 3 / 4 waves per SIMD register budgets -- all slower or spilling;
   // two quadrupeds per wave: 0.843 vs 0.834 ms.)
@@ -244,7 +249,8 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   };
   using KLR = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1>;
   using KP2 = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 2>;
-  if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8>, pf_lds_bytes<KLR, 1, 8>(), 8, 512);
+  if (e->instance == 2) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, PF_KPAIR_QUAD>, pf_lds_bytes<PfKernelQuadSelf, 1, 8>(), 8, 512);
+  else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8>, pf_lds_bytes<KLR, 1, 8>(), 8, 512);
   else launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 1>, pf_lds_bytes<KP2, 2, 1>(), 2, 64);
   PF_HIP_OK(hipGetLastError());
   return 0;

@@ -19,6 +19,7 @@
 #define PF_MAX_CHAIN_DEPTH 8
 #define PF_KSPH 24         /* collision spheres staged per robot (PointFoot instance; the quadruped instance uses 32) */
 #define PF_KSPH_QUAD 32
+#define PF_KPAIR_QUAD 56      /* self-collision capsule pairs of the quadruped instance built with it (4 legs x {thigh, shank, foot}: 54) */
 
 // ------------------------------------------------------------------------------------ small math
 PF_DEV float pf_clip(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -196,7 +197,8 @@ struct PfStepArgs {
   const uint8_t* reset_mask;   // mode 1 only: envs to reset (NULL: all) -- reset_idx(env_ids), point_foot.py:249
 };
 
-template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1>
+// KPR: self-collision capsule pairs the instance is built for (0: built without self-collision)
+template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0)>
 struct PfKernel {
   static constexpr int PF_W = 64 / RPW;         // lanes per robot (pf_simt.h)
   static constexpr bool LR = KIND == PF_KIND_LEGGED_ROBOT;      // LeggedRobot / Anymal semantics (legged_robot.py)
@@ -206,10 +208,13 @@ struct PfKernel {
   static constexpr int NVP = NV | 1;          // odd row stride: per-lane rows hit distinct LDS banks
   static constexpr int MAXC = LR ? PF_MAXC_QUAD : PF_MAXC;
   static constexpr int CREG = MAXC < 6 ? MAXC : 6;      // contact rows the PGS sweep holds in registers; the rest stay in LDS
-  // self-collision capsules / capsule pairs this instance is built for (PointFoot: 2 legs x 4 links; the LeggedRobot tasks
-  // of the reference switch self-collision off, anymal_c_rough_config.py:77)
-  static constexpr int KC = LR ? 1 : 8, KP = LR ? 1 : 16;
-  static constexpr bool SELF = !LR;
+  // self-collision capsules / capsule pairs this instance is built for (PointFoot: 2 legs x 4 links = 8 / 16; a quadruped with
+  // self-collision: 4 legs x {thigh, shank, foot} = 12 / 54, anymal_c_flat_config.py:42; anymal_c_rough switches it off,
+  // anymal_c_rough_config.py:77, and runs the instance built without)
+  static constexpr bool SELF = KPR > 0;
+  static constexpr int KC = SELF ? (LR ? PF_MAX_CAPS : 8) : 1, KP = SELF ? KPR : 1;
+  static constexpr int NCW = (2 * KS + (SELF ? KP : 0) > 64) ? 2 : 1;      // 64-bit words of the contact-candidate set
+  static_assert(2 * KS + (SELF ? KP : 0) <= 128, "the contact-candidate set is at most two 64-bit words");
   static constexpr int CROWS = 3 * MAXC;
   static constexpr int RFREE = CROWS + ND;    // extra right-hand side: free acceleration
   static constexpr int NROWS = RFREE + 1;
@@ -835,7 +840,9 @@ struct PfKernel {
     const int ncand = 2 * nsph + npair;
     auto cand_dist = [&](int cand) { return cand < nsph ? sh.cd[cand] : (cand < 2 * nsph ? sh.cd[KS + cand - nsph] : sh.pd[SELF ? cand - 2 * nsph : 0]); };
     int ncon = 0;
-    unsigned long long cset = 0ull;
+    unsigned long long cset[NCW];      // candidates 0..63 (/ 64..127) -- diagnostic output only
+#pragma unroll
+    for (int w = 0; w < NCW; ++w) cset[w] = 0ull;
 #if !defined(PF_HOST_EMU)
     {
       // compaction by ballot: lane l tests candidates l, l + PF_W, ...; its slot is the number of active candidates before it
@@ -849,20 +856,25 @@ struct PfKernel {
         const int idx = ncon + __popcll(grp & below);
         if (act && idx < MAXC) sh.con_cand[idx] = cand;
         ncon += __popcll(grp);
-        cset |= grp << c0;
+        if (NCW == 1 || c0 < 64) cset[0] |= grp << (c0 & 63); else cset[NCW - 1] |= grp << (c0 & 63);
       }
     }
 #else
     for (int cand = 0; cand < ncand; ++cand)
-      if (cand_dist(cand) < c.contact_offset) { if (ncon < MAXC) sh.con_cand[ncon] = cand; ++ncon; cset |= 1ull << cand; }
+      if (cand_dist(cand) < c.contact_offset) { if (ncon < MAXC) sh.con_cand[ncon] = cand; ++ncon; cset[NCW == 1 ? 0 : cand >> 6] |= 1ull << (cand & 63); }
 #endif
     if (ncon > MAXC) {      // candidates beyond the cap are not contacts: drop them from the reported set
       // ... and count the event: [PF_STAT_CAP_HITS] (env, substep) pairs with more active candidates than the solver keeps,
       // [PF_STAT_CAP_DROPPED] the candidates dropped (tools/train_check.py reports the fraction; profiles/r3_contact_cap.txt)
       PF_ONE { if (B.d_reset_stats) { PF_ATOMIC_ADD(B.d_reset_stats + PF_STAT_CAP_HITS, 1.0f); PF_ATOMIC_ADD(B.d_reset_stats + PF_STAT_CAP_DROPPED, (float)(ncon - MAXC)); } }
-      unsigned long long kept = 0ull, rest = cset;
-      for (int t = 0; t < MAXC; ++t) { kept |= rest & (~rest + 1ull); rest &= rest - 1ull; }
-      cset = kept; ncon = MAXC;
+      int left = MAXC;
+#pragma unroll
+      for (int w = 0; w < NCW; ++w) {
+        unsigned long long kept = 0ull, rest = cset[w];
+        for (; left > 0 && rest != 0ull; --left) { kept |= rest & (~rest + 1ull); rest &= rest - 1ull; }
+        cset[w] = kept;
+      }
+      ncon = MAXC;
     }
     if (B.d_contact_set) {      // diagnostic (parity tests): which candidates were kept, and in which cell / on which face
       unsigned long long cells = 0ull;
@@ -870,7 +882,10 @@ struct PfKernel {
         const int cand = sh.con_cand[ci];
         if (cand < 2 * nsph) { const int cf = sh.ccell[cand < nsph ? cand : cand - nsph]; cells += (unsigned long long)(cand + 1) * (unsigned long long)(cand < nsph ? (cf & ~3) : cf); }
       }
-      PF_ONE { B.d_contact_set[((size_t)env * c.decimation + sub) * 3] = cset; B.d_contact_set[((size_t)env * c.decimation + sub) * 3 + 2] = cells; }
+      PF_ONE {
+        uint64_t* o = B.d_contact_set + ((size_t)env * c.decimation + sub) * PF_CSET_WORDS;
+        o[0] = cset[0]; o[2] = cells; o[3] = NCW > 1 ? cset[NCW - 1] : 0ull;
+      }
     }
     PF_SYNC();
     PF_STAMP(sh, 5);
@@ -954,7 +969,7 @@ struct PfKernel {
     if (B.d_contact_set) {      // diagnostic (parity tests): which joint-limit rows are active
       unsigned long long lset = 0ull;
       for (int k = 0; k < ND; ++k) lset |= (unsigned long long)(sh.lim_side[k] > 0 ? 1 : (sh.lim_side[k] < 0 ? 2 : 0)) << (2 * k);
-      PF_ONE { B.d_contact_set[((size_t)env * c.decimation + sub) * 3 + 1] = lset; }
+      PF_ONE { B.d_contact_set[((size_t)env * c.decimation + sub) * PF_CSET_WORDS + 1] = lset; }
     }
     PF_LANES(k, ND) {
       int side = sh.lim_side[k];

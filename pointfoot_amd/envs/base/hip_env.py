@@ -272,8 +272,8 @@ class HipEnv:
 
     def bind_contact_set(self):
         """Diagnostic (parity tests): have the step kernel export its discrete decisions per substep -- active contact
-        candidates, joint-limit rows, grid cells (PfBuffers.d_contact_set) -- into the returned (N, decimation, 3) tensor."""
-        self.contact_set = torch.zeros(self.num_envs, self.cfg.control.decimation, 3, dtype=torch.int64, device=self.device)
+        candidates, joint-limit rows, grid cells (PfBuffers.d_contact_set) -- into the returned (N, decimation, PF_CSET_WORDS) tensor."""
+        self.contact_set = torch.zeros(self.num_envs, self.cfg.control.decimation, _abi.PF_CSET_WORDS, dtype=torch.int64, device=self.device)
         self._bufs.d_contact_set = _native.ptr(self.contact_set)
         _abi.check(self._lib.pf_bind_buffers(self._h, C.byref(self._bufs)), self._lib)
         return self.contact_set

@@ -65,15 +65,10 @@ def build_model(cfg):
     # Capsules = the two equal-radius end spheres a cylinder / limb box became (urdf.py), or a single sphere; pairs =
     # capsules on different branches of the tree (PhysX never collides a parent with its child; links of one chain
     # cannot reach each other within the joint limits and are left out).
+    # Among the LeggedRobot tasks anymal_c_flat asks for it (anymal_c_flat_config.py:42, applied at legged_robot.py:680): 12 capsules /
+    # 54 pairs on a quadruped, the kernel instance built for them; config 5 (anymal_c_rough) switches it off (anymal_c_rough_config.py:77).
     caps, pairs = [], []
-    legged_robot = hasattr(cfg.env, "num_observations")
-    if getattr(cfg.asset, "self_collisions", 1) == 0 and legged_robot:
-        # only anymal_c_flat asks for it among the LeggedRobot tasks (anymal_c_flat_config.py:42); config 5
-        # (anymal_c_rough) switches it off (anymal_c_rough_config.py:77)
-        import warnings
-        warnings.warn("asset.self_collisions = 0: the LeggedRobot kernel instance is built without self-collision "
-                      "(12 capsules / 54 pairs on a quadruped); the links of this robot can pass through each other")
-    elif getattr(cfg.asset, "self_collisions", 1) == 0:
+    if getattr(cfg.asset, "self_collisions", 1) == 0:
         by_body = {}
         for s, (b, p, r) in enumerate(sph):
             if b != 0 and r > 0.0:

@@ -108,7 +108,7 @@ class HostSim:
         self.hf = None if hf is None else np.ascontiguousarray(hf, np.int16)
         self.terrain_origins = None if terrain_origins is None else np.ascontiguousarray(terrain_origins, np.float32)
         self.stats = np.zeros(_abi.PF_STATS_FLOATS, np.float32)
-        self.contact_set = np.zeros((n, self.c.decimation, 3), np.uint64)  # diagnostic: contact candidates / joint-limit rows / cells per substep
+        self.contact_set = np.zeros((n, self.c.decimation, _abi.PF_CSET_WORDS), np.uint64)  # diagnostic: contact candidates / joint-limit rows / cells per substep
         self.joint_friction = None                                          # (n, nd) float32 or None
         self.bufs = self.make_bufs()
 

@@ -16,6 +16,10 @@ extern "C" int pfe_step(const PfModel* model, const PfConfig* cfg, const PfLayou
     using K = PfKernel<9, 6, 2, PF_KIND_POINTFOOT>;
     static K::Shared sh; static K::SharedRO ro;
     for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, ro, g, env);
+  } else if (cfg->env_kind == PF_KIND_LEGGED_ROBOT && model->nb == 17 && model->nd == 12 && model->nfeet == 4 && model->npair > 0) {
+    using K = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_KPAIR_QUAD>;      // the instance with self-collision
+    static K::Shared sh; static K::SharedRO ro;
+    for (int env = 0; env < cfg->num_envs; ++env) K::run(sh, ro, g, env);
   } else if (cfg->env_kind == PF_KIND_LEGGED_ROBOT && model->nb == 17 && model->nd == 12 && model->nfeet == 4) {
     using K = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>;
     static K::Shared sh; static K::SharedRO ro;

@@ -280,6 +280,39 @@ def test_hip_flat_4096_literal_config():
     hip.close()
 
 
+def test_hip_quadruped_self_contacts_match_oracle():
+    """The quadruped instance built WITH self-collision (12 capsules / 54 pairs, 98 contact candidates: asset.self_collisions = 0,
+    anymal_c_flat_config.py:42) on the GPU, in the crossed-legs scenario of tests/test_physics_invariants.py: same contact sets as the
+    oracle (both words of the candidate set), same motion.  Envs start with different joint angles so that different capsule pairs
+    (feet, shanks, thighs) meet; the invariants themselves (no pass-through, action = reaction) are tests/test_physics_invariants.py's."""
+    from test_physics_invariants import quad_crossing_sim
+    n = 64
+    sim, act = quad_crossing_sim(True, n)
+    rs = np.random.RandomState(4)
+    sim.f("dof_pos", 12)[:] += rs.uniform(-0.25, 0.25, (n, 12)).astype(np.float32) * np.array([0, 1, 1] * 4, np.float32)      # hip flexion / knee
+    ref = sim.clone()
+    hip = common.HipMirror(sim)
+    worst_match, pairs_seen = 1.0, set()
+    L = sim.L
+    keep_cols = np.ones(L.rec_floats, bool); keep_cols[L.contact_forces:L.contact_forces + 51] = False
+    for t in range(16):
+        for k in common.HipMirror.FIELDS:
+            getattr(sim, k)[...] = getattr(ref, k)
+        hip.upload()
+        ref.step("oracle", act, t + 1)
+        hip.step(act, t + 1)
+        m = _same_decisions(sim, ref)
+        worst_match = min(worst_match, float(m.mean()))
+        assert m.mean() >= 62 / 64
+        np.testing.assert_allclose(sim.state[m][:, keep_cols], ref.state[m][:, keep_cols], atol=1e-2, rtol=5e-3)
+        for w0, w3 in zip(sim.contact_set[:, -1, 0], sim.contact_set[:, -1, 3]):
+            bits = (int(w0) >> (2 * sim.model.nsph)) | (int(w3) << (64 - 2 * sim.model.nsph))
+            pairs_seen |= {p for p in range(sim.model.npair) if bits >> p & 1}
+    assert len(pairs_seen) >= 4 and max(pairs_seen) >= 64 - 2 * sim.model.nsph, pairs_seen      # pairs of both words were active
+    common.record_parity("test_hip_quadruped_self_contacts_match_oracle", worst_matched_fraction_per_step=worst_match, pairs_active=len(pairs_seen))
+    hip.close()
+
+
 def test_hip_faces_and_self_contacts_match_oracle():
     """The collision-geometry scenarios of tests/test_physics_invariants.py (riser, crossed legs) on the GPU: same
     contact sets as the oracle, same motion, and the invariants themselves."""

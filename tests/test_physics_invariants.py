@@ -240,3 +240,61 @@ def test_emu_matches_oracle_on_faces_and_self_contacts():
             np.testing.assert_array_equal(a.contact_set, b.contact_set)
             np.testing.assert_allclose(b.state, a.state, atol=5e-3, rtol=1e-3)
             b.state[:] = a.state
+
+
+def quad_crossing_sim(self_collisions, n=2):
+    """ANYmal-C in zero gravity, torque control: all four hip-abduction joints are driven inwards (the quadruped instance with the 12
+    capsules / 54 pairs of asset.self_collisions = 0, anymal_c_flat_config.py:42)."""
+    cfg = common.make_cfg("anymal_c_flat", n, control_type="T", add_noise=False)
+    cfg.domain_rand.push_robots = False
+    cfg.sim.gravity = [0., 0., 0.]
+    cfg.asset.self_collisions = 0 if self_collisions else 1
+    sim = common.HostSim(cfg, n)
+    sim.c.use_actuator_net = 0
+    sim.f("root", 13)[:, 2] = 50.0
+    act = np.zeros((n, 12), np.float32)
+    act[:, 0], act[:, 3], act[:, 6], act[:, 9] = -40.0, 40.0, -40.0, 40.0      # LF / RF / LH / RH hip abduction
+    return sim, act
+
+
+@pytest.mark.parametrize("backend", ["oracle", "emu"])
+def test_quadruped_legs_do_not_pass_through_each_other(backend):
+    sim, act = quad_crossing_sim(True)
+    n, nsph = sim.n, sim.model.nsph
+    assert sim.model.ncap == 12 and sim.model.npair == 54 and sim.c.self_collisions == 1
+    assert 2 * nsph + sim.model.npair > 64      # the candidate set needs its second word
+    pressed = 0
+    for t in range(16):
+        sim.step(backend, act, t + 1)
+        fp = sim.f("feet_pos", 12).reshape(n, 4, 3)
+        # left feet stay on the left of the right feet (front pair, hind pair): 3 cm foot spheres may touch, not pass
+        assert (fp[:, 0, 1] - fp[:, 1, 1] >= 0.06 - 0.004).all() and (fp[:, 2, 1] - fp[:, 3, 1] >= 0.06 - 0.004).all(), f"step {t}: {fp[:, :, 1]}"
+        lo, hi = sim.contact_set[:, -1, 0] >> np.uint64(2 * nsph), sim.contact_set[:, -1, 3]
+        cf = sim.f("contact_forces", 51).reshape(n, 17, 3)
+        if ((lo != 0) & (hi != 0)).all() and (np.abs(cf).sum(axis=(1, 2)) > 1.0).all():
+            pressed += 1
+            # action = reaction inside each pair of legs: LF (bodies 1-4) against RF (5-8), LH (9-12) against RH (13-16)
+            for a, b in ((1, 5), (9, 13)):
+                left, right = cf[:, a:a + 4].sum(axis=1), cf[:, b:b + 4].sum(axis=1)
+                np.testing.assert_allclose(left, -right, atol=1e-3 * np.abs(left).max() + 1e-4)
+                assert (left[:, 1] > 0).all(), "a left leg must be pushed to the left (+y)"
+        assert not np.isnan(sim.state).any()
+    assert pressed >= 4
+    # built without: the same drive swings the legs through each other
+    free, act = quad_crossing_sim(False)
+    assert free.model.npair == 0 and free.c.self_collisions == 0
+    for t in range(8):
+        free.step(backend, act, t + 1)
+    fp = free.f("feet_pos", 12).reshape(n, 4, 3)
+    assert (fp[:, 0, 1] < fp[:, 1, 1]).all() and (fp[:, 2, 1] < fp[:, 3, 1]).all()
+
+
+def test_emu_matches_oracle_on_quadruped_self_contacts():
+    a, act = quad_crossing_sim(True, 4)
+    b = a.clone()
+    for t in range(14):
+        a.step("oracle", act, t + 1)
+        b.step("emu", act, t + 1)
+        np.testing.assert_array_equal(a.contact_set, b.contact_set)
+        np.testing.assert_allclose(b.state, a.state, atol=5e-3, rtol=1e-3)
+        b.state[:] = a.state
