@@ -31,9 +31,9 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // WPB wavefronts per workgroup (each with RPW robots) share one read-only block (model, actuator parameters) in LDS; the
 // rest of the LDS is per robot.  WAVES = waves per SIMD the register budget is sized for.  LDS comes as dynamic shared
 // memory (the quadruped workgroup of 8 robots needs ~145 KB, above the static limit).
-template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0)>
+template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0), int NBD = NB>
 __global__ __launch_bounds__(64 * WPB, WPB == 1 ? WAVES : 1) void pf_step_kernel(const PfModel* __restrict__ model, const PfConfig* __restrict__ cfg, PfStepArgs g) {
-  using K = PfKernel<NB, ND, NF, KIND, KS, RPW, KPR>;
+  using K = PfKernel<NB, ND, NF, KIND, KS, RPW, KPR, NBD>;
   extern __shared__ __attribute__((aligned(16))) unsigned char pf_lds[];
   typename K::SharedRO& ro = *reinterpret_cast<typename K::SharedRO*>(pf_lds);
   typename K::Shared* sh = reinterpret_cast<typename K::Shared*>(pf_lds + ((sizeof(typename K::SharedRO) + 15) & ~size_t(15)));
@@ -56,7 +56,8 @@ struct PfEnv {
   PfConfig cfg;
   PfLayout layout;
   PfBuffers bufs;
-  PfModel* d_model = nullptr;
+  PfModel* d_model = nullptr;     // the model the kernel integrates: fixed-joint bodies lumped into their parents (pf_lump.h)
+  PfLump* d_lump = nullptr;       // ... and its reporting tables
   PfConfig* d_cfg = nullptr;
   int device = 0;
   bool bound = false;
@@ -106,7 +107,11 @@ static int pf_instance(const PfModel* m, const PfConfig* c) {
   if (c->env_kind == PF_KIND_LEGGED_ROBOT && m->nb == 17 && m->nd == 12 && m->nfeet == 4) return (c->self_collisions && m->npair > 0) ? 2 : 1;
   return -1;
 }
-using PfKernelQuadSelf = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_KPAIR_QUAD>;
+// dynamics on the models with their feet lumped into the shanks: 9 -> 7 bodies (PointFoot), 17 -> 13 (quadrupeds)
+constexpr int PF_NBD_POINTFOOT = 7, PF_NBD_QUAD = 13;
+using PfKernelPoint = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 16, PF_NBD_POINTFOOT>;
+using PfKernelQuad = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 0, PF_NBD_QUAD>;
+using PfKernelQuadSelf = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_KPAIR_QUAD, PF_NBD_QUAD>;
 static int pf_validate(const PfModel* m, const PfConfig* c) {
   int inst = pf_instance(m, c);
   if (inst < 0) {
@@ -124,7 +129,7 @@ static int pf_validate(const PfModel* m, const PfConfig* c) {
     return 1;
   }
   if (m->ncap < 0 || m->npair < 0 || m->ncap > PF_MAX_CAPS || m->npair > PF_MAX_PAIRS ||
-      (inst == 0 && (m->ncap > PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::KC || m->npair > PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::KP)) ||
+      (inst == 0 && (m->ncap > PfKernelPoint::KC || m->npair > PfKernelPoint::KP)) ||
       (inst == 1 && c->self_collisions) ||
       (inst == 2 && (m->ncap > PfKernelQuadSelf::KC || m->npair > PfKernelQuadSelf::KP))) {
     pf_set_error("pf_create: self-collision geometry outside the compiled limits (PointFoot: 8 capsules / 16 pairs; LeggedRobot: 16 / 56; "
@@ -149,13 +154,20 @@ PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device) {
   e->model = *model; e->cfg = *cfg; e->device = device;
   pf_compute_layout(model, cfg, &e->layout);
   e->instance = pf_instance(model, cfg);
-  bool lay_ok = e->instance == 0 ? PfKernel<9, 6, 2, PF_KIND_POINTFOOT>::layout_matches(e->layout)
-              : e->instance == 1 ? PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD>::layout_matches(e->layout)
+  bool lay_ok = e->instance == 0 ? PfKernelPoint::layout_matches(e->layout)
+              : e->instance == 1 ? PfKernelQuad::layout_matches(e->layout)
                                  : PfKernelQuadSelf::layout_matches(e->layout);
   if (!lay_ok) { pf_set_error("pf_create: record layout differs from the kernel's compile-time layout"); delete e; return nullptr; }
-  if (hipSetDevice(device) != hipSuccess || hipMalloc(&e->d_model, sizeof(PfModel)) != hipSuccess ||
+  PfModel lumped; PfLump lump;
+  pf_lump_model(model, &lumped, &lump);
+  if (lumped.nb != (e->instance == 0 ? PF_NBD_POINTFOOT : PF_NBD_QUAD)) {
+    pf_set_error("pf_create: the model does not reduce to the kernel instance's body count (PointFoot: 9 bodies with 2 fixed feet; LeggedRobot: 17 with 4)");
+    delete e; return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&e->d_model, sizeof(PfModel)) != hipSuccess || hipMalloc(&e->d_lump, sizeof(PfLump)) != hipSuccess ||
       hipMalloc(&e->d_cfg, sizeof(PfConfig)) != hipSuccess ||
-      hipMemcpy(e->d_model, model, sizeof(PfModel), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(e->d_model, &lumped, sizeof(PfModel), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(e->d_lump, &lump, sizeof(PfLump), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(e->d_cfg, cfg, sizeof(PfConfig), hipMemcpyHostToDevice) != hipSuccess) {
     pf_set_error("pf_create: HIP device allocation failed (is a GPU visible?)");
     delete e;
@@ -167,6 +179,7 @@ PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device) {
 void pf_destroy(PfEnv* e) {
   if (!e) return;
   if (e->d_model) (void)hipFree(e->d_model);
+  if (e->d_lump) (void)hipFree(e->d_lump);
   if (e->d_cfg) (void)hipFree(e->d_cfg);
   delete e;
 }
@@ -223,7 +236,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   if (mode == 0 && !d_actions) { pf_set_error("pf_step: actions pointer is NULL"); return 1; }
   { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != e->device) { pf_set_error("pf_step: the calling thread's current HIP device is not the env's device (torch.cuda.set_device)"); return 1; } }
   PfStepArgs g;
-  g.model = e->d_model; g.cfg = e->d_cfg; g.L = e->layout; g.b = e->bufs;
+  g.model = e->d_model; g.lump = e->d_lump; g.cfg = e->d_cfg; g.L = e->layout; g.b = e->bufs;
   if (inject) g.inj = *inject; else std::memset(&g.inj, 0, sizeof(g.inj));
   if (g.inj.d_root && !(g.inj.d_dof_pre && g.inj.d_dof_post && g.inj.d_contact && g.inj.d_feet_pos)) {
     pf_set_error("pf_step: incomplete injected sim state"); return 1;
@@ -247,11 +260,9 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
     if (lds > 64 * 1024 && !raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
     hipLaunchKernelGGL(kern, dim3((N + robots_per_block - 1) / robots_per_block), dim3(threads), lds, s, e->d_model, e->d_cfg, g);
   };
-  using KLR = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1>;
-  using KP2 = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 2>;
-  if (e->instance == 2) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, PF_KPAIR_QUAD>, pf_lds_bytes<PfKernelQuadSelf, 1, 8>(), 8, 512);
-  else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8>, pf_lds_bytes<KLR, 1, 8>(), 8, 512);
-  else launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 1>, pf_lds_bytes<KP2, 2, 1>(), 2, 64);
+  if (e->instance == 2) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, PF_KPAIR_QUAD, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuadSelf, 1, 8>(), 8, 512);
+  else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, 0, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuad, 1, 8>(), 8, 512);
+  else launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 1, 16, PF_NBD_POINTFOOT>, pf_lds_bytes<PfKernelPoint, 2, 1>(), 2, 64);
   PF_HIP_OK(hipGetLastError());
   return 0;
 }

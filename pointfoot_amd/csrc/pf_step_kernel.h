@@ -17,6 +17,7 @@
 #define PF_MAXC_QUAD 10
 #define PF_MAX_CHAINS 8
 #define PF_MAX_CHAIN_DEPTH 8
+#include "pf_lump.h"
 #define PF_KSPH 24         /* collision spheres staged per robot (PointFoot instance; the quadruped instance uses 32) */
 #define PF_KSPH_QUAD 32
 #define PF_KPAIR_QUAD 56      /* self-collision capsule pairs of the quadruped instance built with it (4 legs x {thigh, shank, foot}: 54) */
@@ -195,10 +196,13 @@ struct PfStepArgs {
   unsigned* stamps;       // diagnostic build only, else NULL
   float* stats_next;      // next step's statistics slot, cleared by this launch (NULL: the host clears slots itself)
   const uint8_t* reset_mask;   // mode 1 only: envs to reset (NULL: all) -- reset_idx(env_ids), point_foot.py:249
+  const PfLump* lump;          // reporting tables of a model with lumped fixed bodies (pf_lump.h; device copy), NULL: `model` is as handed over
 };
 
 // KPR: self-collision capsule pairs the instance is built for (0: built without self-collision)
-template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0)>
+// NBD: bodies of the model the dynamics run on -- the robot with its fixed-joint bodies (the feet) lumped into their parents
+// (pf_lump.h); NB stays the number of bodies the record reports on (contact_forces, feet)
+template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0), int NBD = NB>
 struct PfKernel {
   static constexpr int PF_W = 64 / RPW;         // lanes per robot (pf_simt.h)
   static constexpr bool LR = KIND == PF_KIND_LEGGED_ROBOT;      // LeggedRobot / Anymal semantics (legged_robot.py)
@@ -268,16 +272,17 @@ struct PfKernel {
   // tables are indexed by lane, so reading them from global memory would put an L2 round trip into every phase.
   struct ModelS {
     int nsph, n_term, n_pen;
-    int parent[NB], depth[NB], subtree[NB], dof_of_body[NB], body_of_dof[ND], feet_body[NF];
+    int parent[NBD], depth[NBD], subtree[NBD], dof_of_body[NBD], body_of_dof[ND], feet_body[NF];
+    int feet_dyn[NF]; float feet_off[NF][3];      // carrier body of foot f and the foot frame's origin on it (pf_lump.h)
     int term_body[PF_MAX_TERM], pen_body[PF_MAX_PEN];
-    float joint_pos[NB][3], joint_rot[NB][9], joint_axis[NB][3];
-    float mass[NB], com[NB][3], inertia[NB][6];
+    float joint_pos[NBD][3], joint_rot[NBD][9], joint_axis[NBD][3];
+    float mass[NBD], com[NBD][3], inertia[NBD][6];
     float q_lo[ND], q_hi[ND], vel_limit[ND];
-    int sph_body[KS];
+    int sph_body[KS], sph_rep[KS];                // body that carries sphere s / body its contact force is reported on
     float sph_pos[KS][3], sph_radius[KS];
     int ncap, npair, cap_s0[KC], cap_s1[KC], pair_a[KP], pair_b[KP];
     // root-to-leaf chains (one lane walks one chain in forward kinematics) and per-body 'fixed rotation is identity' flags
-    int nchain, chain_len[PF_MAX_CHAINS], chain[PF_MAX_CHAINS][PF_MAX_CHAIN_DEPTH], rot_ident[NB];
+    int nchain, chain_len[PF_MAX_CHAINS], chain[PF_MAX_CHAINS][PF_MAX_CHAIN_DEPTH], rot_ident[NBD];
   };
 
   // read-only per launch, identical for every robot: one copy per workgroup, shared by all its robots
@@ -292,14 +297,14 @@ struct PfKernel {
 #endif
     float rec[REC_MAX];
     float gates[LR ? ND * 32 : 1];            // LSTM gate pre-activations
-    float Rw[NB][9], r[NB][3], ax[NB][3];
+    float Rw[NBD][9], r[NBD][3], ax[NBD][3];
     // The dynamics scratch (dead once the mass matrix and the bias are built) and the contact candidates (born after the
     // factorisation, dead after the contact rows) share storage.
     union {
       struct {
-        float Sj[NB][6], V[NB][6], A[NB][6];      // {ang, lin@O}
-        float I[NB][10], Ic[NB][10];
-        float f[NB][6], fc[NB][6];                // {moment@O, force}
+        float Sj[NBD][6], V[NBD][6], A[NBD][6];      // {ang, lin@O}
+        float I[NBD][10], Ic[NBD][10];
+        float f[NBD][6], fc[NBD][6];                // {moment@O, force}
         float F[ND][6];
       };
       struct {
@@ -628,7 +633,7 @@ struct PfKernel {
     kinematics<true>(sh, m, c, L);
     PF_STAMP(sh, 1);
     // ---- per-body spatial inertia about O and bias wrench
-    PF_LANES(i, NB) {
+    PF_LANES(i, NBD) {
       float mass = m.mass[i];
       float cl[3] = {m.com[i][0], m.com[i][1], m.com[i][2]};
       float Il[6];
@@ -668,7 +673,7 @@ struct PfKernel {
     }
     PF_SYNC();
     // ---- composites over DFS-contiguous subtrees: one lane per (body, component)
-    PF_LANES(e, NB * 16) {
+    PF_LANES(e, NBD * 16) {
       int i = e >> 4, t = e & 15;
       int end = i + m.subtree[i];
       float acc = 0.0f;
@@ -894,17 +899,18 @@ struct PfKernel {
     PF_LANES(rr, 3 * ncon) {
       int ci = rr / 3, d = rr - 3 * ci;
       const int cand = sh.con_cand[ci];
-      int i, ib = -1;
+      int i, ib = -1, irep, ibrep = -1;      // bodies of the dynamics / bodies the force is reported on
       float n[3], xc[3], dist;
       if (cand < 2 * nsph) {
         const int s = cand < nsph ? cand : cand - nsph, slot = cand < nsph ? cand : KS + s;
-        i = m.sph_body[s];
+        i = m.sph_body[s]; irep = m.sph_rep[s];
         const float rad = m.sph_radius[s];
         dist = sh.cd[slot];
         for (int t = 0; t < 3; ++t) { n[t] = sh.cn[slot][t]; xc[t] = sh.sphc[s][t] - rad * n[t]; }
       } else {
         const int p = SELF ? cand - 2 * nsph : 0;
         i = m.sph_body[m.cap_s0[m.pair_a[p]]]; ib = m.sph_body[m.cap_s0[m.pair_b[p]]];
+        irep = m.sph_rep[m.cap_s0[m.pair_a[p]]]; ibrep = m.sph_rep[m.cap_s0[m.pair_b[p]]];
         dist = sh.pd[p];
         for (int t = 0; t < 3; ++t) { n[t] = sh.pn[p][t]; xc[t] = sh.px[p][t]; }
       }
@@ -916,7 +922,7 @@ struct PfKernel {
       float dd[3];
       for (int t = 0; t < 3; ++t) dd[t] = d == 0 ? n[t] : (d == 1 ? t1[t] : t2[t]);
       for (int t = 0; t < 3; ++t) sh.cdir[ci][3 * d + t] = dd[t];
-      if (d == 0) { sh.cbody[ci] = i; sh.cbody_b[ci] = ib; }
+      if (d == 0) { sh.cbody[ci] = irep; sh.cbody_b[ci] = ibrep; }
       float row[NV];
 #pragma unroll
       for (int a = 0; a < NV; ++a) row[a] = 0.0f;
@@ -1358,7 +1364,7 @@ struct PfKernel {
 #if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
     if (threadIdx.x == 0) { sh.stamp_last = __builtin_amdgcn_s_memtime(); for (int t = 0; t < PF_NSTAMP; ++t) sh.stamp_acc[t] = 0; }
 #endif
-    PF_LANES(i, NB) {
+    PF_LANES(i, NBD) {
       ms.parent[i] = gm.parent[i]; ms.depth[i] = gm.depth[i]; ms.subtree[i] = gm.subtree[i]; ms.dof_of_body[i] = gm.dof_of_body[i];
       ms.mass[i] = gm.mass[i];
       for (int t = 0; t < 3; ++t) { ms.joint_pos[i][t] = gm.joint_pos[i][t]; ms.joint_axis[i][t] = gm.joint_axis[i][t]; ms.com[i][t] = gm.com[i][t]; }
@@ -1368,9 +1374,14 @@ struct PfKernel {
     PF_LANES(k, ND) { ms.body_of_dof[k] = gm.body_of_dof[k]; ms.q_lo[k] = gm.q_lo[k]; ms.q_hi[k] = gm.q_hi[k]; ms.vel_limit[k] = gm.vel_limit[k]; }
     PF_LANES(s2, KS) {
       ms.sph_body[s2] = gm.sph_body[s2]; ms.sph_radius[s2] = gm.sph_radius[s2];
+      ms.sph_rep[s2] = g.lump ? g.lump->sph_rep[s2] : gm.sph_body[s2];
       for (int t = 0; t < 3; ++t) ms.sph_pos[s2][t] = gm.sph_pos[s2][t];
     }
-    PF_LANES(f, NF) ms.feet_body[f] = gm.feet_body[f];
+    PF_LANES(f, NF) {
+      ms.feet_body[f] = gm.feet_body[f];
+      ms.feet_dyn[f] = g.lump ? g.lump->feet_dyn[f] : gm.feet_body[f];
+      for (int t = 0; t < 3; ++t) ms.feet_off[f][t] = g.lump ? g.lump->feet_off[f][t] : 0.0f;
+    }
     PF_LANES(t, KC) { ms.cap_s0[t] = gm.cap_s0[t]; ms.cap_s1[t] = gm.cap_s1[t]; }
     PF_LANES(t, KP) { ms.pair_a[t] = gm.pair_a[t]; ms.pair_b[t] = gm.pair_b[t]; }
     PF_LANES(t, PF_MAX_TERM) ms.term_body[t] = gm.term_body[t];
@@ -1385,7 +1396,7 @@ struct PfKernel {
     PF_SYNC();
     if (need_chains) {
       // chains: one per leaf body (subtree == 1); chain[c] lists the bodies from the base's child down to the leaf
-      PF_LANES(b, NB) {
+      PF_LANES(b, NBD) {
         bool ident = true;
         for (int t = 0; t < 9; ++t) ident = ident && (ms.joint_rot[b][t] == ((t % 4 == 0) ? 1.0f : 0.0f));
         ms.rot_ident[b] = ident ? 1 : 0;
@@ -1401,7 +1412,7 @@ struct PfKernel {
         }
       }
       int nch = 0;
-      for (int j = 1; j < NB; ++j) nch += ms.subtree[j] == 1 ? 1 : 0;
+      for (int j = 1; j < NBD; ++j) nch += ms.subtree[j] == 1 ? 1 : 0;
       PF_ONE { ms.nchain = nch < PF_MAX_CHAINS ? nch : PF_MAX_CHAINS; }
       PF_SYNC();
     }
@@ -1464,7 +1475,12 @@ struct PfKernel {
         PF_SYNC();
       }
       kinematics<false>(sh, m, c, L);
-      PF_LANES(e, NF * 3) { int f = e / 3, t = e - 3 * f; S[LC::feet_pos + e] = S[LC::root + t] + sh.r[m.feet_body[f]][t]; }
+      PF_LANES(e, NF * 3) {      // origin of the foot's link frame: on its carrier body at feet_off
+        // (same operations, same order as the kinematics chain would use for a body of its own: r_foot = r_carrier + R_carrier off)
+        const int f = e / 3, t = e - 3 * f, b = m.feet_dyn[f];
+        float ro[3]; pf_mat_vec(sh.Rw[b], m.feet_off[f], ro);
+        S[LC::feet_pos + e] = S[LC::root + t] + (sh.r[b][t] + ro[t]);
+      }
       PF_SYNC();
     }
     PF_STAMP(sh, 13);

@@ -43,7 +43,7 @@ def oracle_lib():
 def emu_lib():
     out = os.path.join(ROOT, "tests", "emu", "_build", "libpf_emu.so")
     srcs = [os.path.join(ROOT, "tests", "emu", "pf_emu.cpp")] + [
-        os.path.join(ROOT, "pointfoot_amd", "csrc", f) for f in ("pf_step_kernel.h", "pf_simt.h", "pf_layout.h")] + [
+        os.path.join(ROOT, "pointfoot_amd", "csrc", f) for f in ("pf_step_kernel.h", "pf_simt.h", "pf_layout.h", "pf_lump.h")] + [
         os.path.join(ROOT, "include", "pointfoot_hip.h")]
     _build(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "tests/emu/pf_emu.cpp", "-o", out],
            out, srcs)
