@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
+#include <vector>
 
 #include "../../include/pointfoot_hip.h"
 #include "../../include/pointfoot_hip_dev.h"
@@ -32,12 +34,12 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // rest of the LDS is per robot.  WAVES = waves per SIMD the register budget is sized for.  LDS comes as dynamic shared
 // memory (the quadruped workgroup of 8 robots needs ~145 KB, above the static limit).
 template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0), int NBD = NB>
-__global__ __launch_bounds__(64 * WPB, WPB == 1 ? WAVES : 1) void pf_step_kernel(const PfModel* __restrict__ model, const PfConfig* __restrict__ cfg, PfStepArgs g) {
+__global__ __launch_bounds__(64 * WPB, WPB == 1 ? WAVES : 1) void pf_step_kernel(const void* __restrict__ packed, const PfConfig* __restrict__ cfg, PfStepArgs g) {
   using K = PfKernel<NB, ND, NF, KIND, KS, RPW, KPR, NBD>;
   extern __shared__ __attribute__((aligned(16))) unsigned char pf_lds[];
   typename K::SharedRO& ro = *reinterpret_cast<typename K::SharedRO*>(pf_lds);
   typename K::Shared* sh = reinterpret_cast<typename K::Shared*>(pf_lds + ((sizeof(typename K::SharedRO) + 15) & ~size_t(15)));
-  g.model = model; g.cfg = cfg;
+  g.packed = packed; g.cfg = cfg;
   // the slot the *next* launch accumulates into is cleared here, so a rollout needs no memset between steps
   if (blockIdx.x == 0 && g.stats_next && threadIdx.x < PF_STATS_FLOATS) g.stats_next[threadIdx.x] = 0.0f;
   // each group of 64 / RPW lanes runs the phase program on its own robot and its own LDS block
@@ -56,8 +58,8 @@ struct PfEnv {
   PfConfig cfg;
   PfLayout layout;
   PfBuffers bufs;
-  PfModel* d_model = nullptr;     // the model the kernel integrates: fixed-joint bodies lumped into their parents (pf_lump.h)
-  PfLump* d_lump = nullptr;       // ... and its reporting tables
+  void* d_packed = nullptr;       // the model the kernel integrates -- fixed-joint bodies lumped into their parents (pf_lump.h) -- packed
+                                  // in the instance's LDS layout (PfKernel::pack_model): a launch stages it with one flat copy
   PfConfig* d_cfg = nullptr;
   int device = 0;
   bool bound = false;
@@ -164,10 +166,16 @@ PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device) {
     pf_set_error("pf_create: the model does not reduce to the kernel instance's body count (PointFoot: 9 bodies with 2 fixed feet; LeggedRobot: 17 with 4)");
     delete e; return nullptr;
   }
-  if (hipSetDevice(device) != hipSuccess || hipMalloc(&e->d_model, sizeof(PfModel)) != hipSuccess || hipMalloc(&e->d_lump, sizeof(PfLump)) != hipSuccess ||
+  std::vector<unsigned char> img;
+  auto pack = [&](auto* kernel_type) {
+    using K = std::remove_pointer_t<decltype(kernel_type)>;
+    img.resize(sizeof(typename K::ModelS));
+    K::pack_model(lumped, lump, *reinterpret_cast<typename K::ModelS*>(img.data()));
+  };
+  if (e->instance == 0) pack((PfKernelPoint*)nullptr); else if (e->instance == 1) pack((PfKernelQuad*)nullptr); else pack((PfKernelQuadSelf*)nullptr);
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&e->d_packed, img.size()) != hipSuccess ||
       hipMalloc(&e->d_cfg, sizeof(PfConfig)) != hipSuccess ||
-      hipMemcpy(e->d_model, &lumped, sizeof(PfModel), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(e->d_lump, &lump, sizeof(PfLump), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(e->d_packed, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(e->d_cfg, cfg, sizeof(PfConfig), hipMemcpyHostToDevice) != hipSuccess) {
     pf_set_error("pf_create: HIP device allocation failed (is a GPU visible?)");
     delete e;
@@ -178,8 +186,7 @@ PfEnv* pf_create(const PfModel* model, const PfConfig* cfg, int32_t device) {
 
 void pf_destroy(PfEnv* e) {
   if (!e) return;
-  if (e->d_model) (void)hipFree(e->d_model);
-  if (e->d_lump) (void)hipFree(e->d_lump);
+  if (e->d_packed) (void)hipFree(e->d_packed);
   if (e->d_cfg) (void)hipFree(e->d_cfg);
   delete e;
 }
@@ -236,7 +243,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   if (mode == 0 && !d_actions) { pf_set_error("pf_step: actions pointer is NULL"); return 1; }
   { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != e->device) { pf_set_error("pf_step: the calling thread's current HIP device is not the env's device (torch.cuda.set_device)"); return 1; } }
   PfStepArgs g;
-  g.model = e->d_model; g.lump = e->d_lump; g.cfg = e->d_cfg; g.L = e->layout; g.b = e->bufs;
+  g.packed = e->d_packed; g.cfg = e->d_cfg; g.L = e->layout; g.b = e->bufs;
   if (inject) g.inj = *inject; else std::memset(&g.inj, 0, sizeof(g.inj));
   if (g.inj.d_root && !(g.inj.d_dof_pre && g.inj.d_dof_post && g.inj.d_contact && g.inj.d_feet_pos)) {
     pf_set_error("pf_step: incomplete injected sim state"); return 1;
@@ -258,7 +265,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   auto launch = [&](auto kern, size_t lds, int robots_per_block, int threads) {
     static bool raised = false;          // one kernel per env handle in practice; raising the limit again is harmless
     if (lds > 64 * 1024 && !raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
-    hipLaunchKernelGGL(kern, dim3((N + robots_per_block - 1) / robots_per_block), dim3(threads), lds, s, e->d_model, e->d_cfg, g);
+    hipLaunchKernelGGL(kern, dim3((N + robots_per_block - 1) / robots_per_block), dim3(threads), lds, s, e->d_packed, e->d_cfg, g);
   };
   if (e->instance == 2) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, PF_KPAIR_QUAD, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuadSelf, 1, 8>(), 8, 512);
   else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, 0, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuad, 1, 8>(), 8, 512);

@@ -185,7 +185,7 @@ PF_DEV float pf_philox_slot(uint32_t k0, uint32_t k1, uint32_t env, uint32_t ste
 #endif
 
 struct PfStepArgs {
-  const PfModel* model;   // device copy
+  const void* packed;     // the instance's ModelS image (PfKernel::pack_model), device copy: staged into LDS by one flat copy
   const PfConfig* cfg;    // device copy
   PfLayout L;
   PfBuffers b;
@@ -196,7 +196,6 @@ struct PfStepArgs {
   unsigned* stamps;       // diagnostic build only, else NULL
   float* stats_next;      // next step's statistics slot, cleared by this launch (NULL: the host clears slots itself)
   const uint8_t* reset_mask;   // mode 1 only: envs to reset (NULL: all) -- reset_idx(env_ids), point_foot.py:249
-  const PfLump* lump;          // reporting tables of a model with lumped fixed bodies (pf_lump.h; device copy), NULL: `model` is as handed over
 };
 
 // KPR: self-collision capsule pairs the instance is built for (0: built without self-collision)
@@ -284,6 +283,49 @@ struct PfKernel {
     // root-to-leaf chains (one lane walks one chain in forward kinematics) and per-body 'fixed rotation is identity' flags
     int nchain, chain_len[PF_MAX_CHAINS], chain[PF_MAX_CHAINS][PF_MAX_CHAIN_DEPTH], rot_ident[NBD];
   };
+
+  // Host side (pf_create; the host build of the step program): ModelS from the model with lumped fixed bodies and its
+  // reporting tables (pf_lump.h), chains and identity flags included -- the launch only copies the image into LDS.
+  static void pack_model(const PfModel& gm, const PfLump& lump, ModelS& ms) {
+    std::memset(&ms, 0, sizeof(ModelS));
+    for (int i = 0; i < NBD; ++i) {
+      ms.parent[i] = gm.parent[i]; ms.depth[i] = gm.depth[i]; ms.subtree[i] = gm.subtree[i]; ms.dof_of_body[i] = gm.dof_of_body[i];
+      ms.mass[i] = gm.mass[i];
+      for (int t = 0; t < 3; ++t) { ms.joint_pos[i][t] = gm.joint_pos[i][t]; ms.joint_axis[i][t] = gm.joint_axis[i][t]; ms.com[i][t] = gm.com[i][t]; }
+      for (int t = 0; t < 9; ++t) ms.joint_rot[i][t] = gm.joint_rot[i][t];
+      for (int t = 0; t < 6; ++t) ms.inertia[i][t] = gm.inertia[i][t];
+    }
+    for (int k = 0; k < ND; ++k) { ms.body_of_dof[k] = gm.body_of_dof[k]; ms.q_lo[k] = gm.q_lo[k]; ms.q_hi[k] = gm.q_hi[k]; ms.vel_limit[k] = gm.vel_limit[k]; }
+    for (int s2 = 0; s2 < KS; ++s2) {
+      ms.sph_body[s2] = gm.sph_body[s2]; ms.sph_radius[s2] = gm.sph_radius[s2]; ms.sph_rep[s2] = lump.sph_rep[s2];
+      for (int t = 0; t < 3; ++t) ms.sph_pos[s2][t] = gm.sph_pos[s2][t];
+    }
+    for (int f = 0; f < NF; ++f) {
+      ms.feet_body[f] = gm.feet_body[f]; ms.feet_dyn[f] = lump.feet_dyn[f];
+      for (int t = 0; t < 3; ++t) ms.feet_off[f][t] = lump.feet_off[f][t];
+    }
+    for (int t = 0; t < KC && t < PF_MAX_CAPS; ++t) { ms.cap_s0[t] = gm.cap_s0[t]; ms.cap_s1[t] = gm.cap_s1[t]; }
+    for (int t = 0; t < KP && t < PF_MAX_PAIRS; ++t) { ms.pair_a[t] = gm.pair_a[t]; ms.pair_b[t] = gm.pair_b[t]; }
+    for (int t = 0; t < PF_MAX_TERM; ++t) ms.term_body[t] = gm.term_body[t];
+    for (int t = 0; t < PF_MAX_PEN; ++t) ms.pen_body[t] = gm.pen_body[t];
+    ms.nsph = gm.nsph; ms.n_term = gm.n_term; ms.n_pen = gm.n_pen; ms.ncap = gm.ncap; ms.npair = gm.npair;
+    // chains: one per leaf body (subtree == 1); chain[c] lists the bodies from the base's child down to the leaf
+    int nch = 0;
+    for (int b = 0; b < NBD; ++b) {
+      bool ident = true;
+      for (int t = 0; t < 9; ++t) ident = ident && (ms.joint_rot[b][t] == ((t % 4 == 0) ? 1.0f : 0.0f));
+      ms.rot_ident[b] = ident ? 1 : 0;
+      if (b > 0 && ms.subtree[b] == 1) {
+        const int ci = nch++, d = ms.depth[b];
+        if (ci < PF_MAX_CHAINS && d <= PF_MAX_CHAIN_DEPTH) {
+          ms.chain_len[ci] = d;
+          int j = b;
+          for (int kk = d - 1; kk >= 0; --kk) { ms.chain[ci][kk] = j; j = ms.parent[j]; }
+        }
+      }
+    }
+    ms.nchain = nch < PF_MAX_CHAINS ? nch : PF_MAX_CHAINS;
+  }
 
   // read-only per launch, identical for every robot: one copy per workgroup, shared by all its robots
   struct SharedRO {
@@ -1358,64 +1400,23 @@ struct PfKernel {
   // Every wavefront stages the workgroup's read-only block itself (same values from every wave: no cross-wave ordering is
   // needed, so PF_SYNC stays wave-local and robots of one workgroup may diverge freely).
   PF_DEV void run(Shared& sh, SharedRO& ro, const PfStepArgs& g, int env) {
-    const PfModel& gm = *g.model; const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
+    const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
     ModelS& ms = ro.mdl;
     if (g.mode == 1 && g.reset_mask && !g.reset_mask[env]) return;      // reset_idx(env_ids): this env is not in the subset
 #if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
     if (threadIdx.x == 0) { sh.stamp_last = __builtin_amdgcn_s_memtime(); for (int t = 0; t < PF_NSTAMP; ++t) sh.stamp_acc[t] = 0; }
 #endif
-    PF_LANES(i, NBD) {
-      ms.parent[i] = gm.parent[i]; ms.depth[i] = gm.depth[i]; ms.subtree[i] = gm.subtree[i]; ms.dof_of_body[i] = gm.dof_of_body[i];
-      ms.mass[i] = gm.mass[i];
-      for (int t = 0; t < 3; ++t) { ms.joint_pos[i][t] = gm.joint_pos[i][t]; ms.joint_axis[i][t] = gm.joint_axis[i][t]; ms.com[i][t] = gm.com[i][t]; }
-      for (int t = 0; t < 9; ++t) ms.joint_rot[i][t] = gm.joint_rot[i][t];
-      for (int t = 0; t < 6; ++t) ms.inertia[i][t] = gm.inertia[i][t];
+    {     // the model in its LDS layout, packed once on the host (pack_model): one flat copy, every load in flight at once
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(g.packed);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(&ms);
+      PF_LANES(i, (int)(sizeof(ModelS) / 4)) dst[i] = src[i];
     }
-    PF_LANES(k, ND) { ms.body_of_dof[k] = gm.body_of_dof[k]; ms.q_lo[k] = gm.q_lo[k]; ms.q_hi[k] = gm.q_hi[k]; ms.vel_limit[k] = gm.vel_limit[k]; }
-    PF_LANES(s2, KS) {
-      ms.sph_body[s2] = gm.sph_body[s2]; ms.sph_radius[s2] = gm.sph_radius[s2];
-      ms.sph_rep[s2] = g.lump ? g.lump->sph_rep[s2] : gm.sph_body[s2];
-      for (int t = 0; t < 3; ++t) ms.sph_pos[s2][t] = gm.sph_pos[s2][t];
-    }
-    PF_LANES(f, NF) {
-      ms.feet_body[f] = gm.feet_body[f];
-      ms.feet_dyn[f] = g.lump ? g.lump->feet_dyn[f] : gm.feet_body[f];
-      for (int t = 0; t < 3; ++t) ms.feet_off[f][t] = g.lump ? g.lump->feet_off[f][t] : 0.0f;
-    }
-    PF_LANES(t, KC) { ms.cap_s0[t] = gm.cap_s0[t]; ms.cap_s1[t] = gm.cap_s1[t]; }
-    PF_LANES(t, KP) { ms.pair_a[t] = gm.pair_a[t]; ms.pair_b[t] = gm.pair_b[t]; }
-    PF_LANES(t, PF_MAX_TERM) ms.term_body[t] = gm.term_body[t];
-    PF_LANES(t, PF_MAX_PEN) ms.pen_body[t] = gm.pen_body[t];
-    PF_ONE { ms.nsph = gm.nsph; ms.n_term = gm.n_term; ms.n_pen = gm.n_pen; ms.ncap = gm.ncap; ms.npair = gm.npair; }
     if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { PF_LANES(i, PF_ACT_PARAMS) ro.act[i] = B.d_actuator_params[i]; } }
     const ModelS& m = ms;
     float* S = sh.rec;
-    bool need_chains = true;
     float* grow = B.d_state + (size_t)env * L.rec_floats;
     PF_LANES(i, L.rec_floats) S[i] = grow[i];
     PF_SYNC();
-    if (need_chains) {
-      // chains: one per leaf body (subtree == 1); chain[c] lists the bodies from the base's child down to the leaf
-      PF_LANES(b, NBD) {
-        bool ident = true;
-        for (int t = 0; t < 9; ++t) ident = ident && (ms.joint_rot[b][t] == ((t % 4 == 0) ? 1.0f : 0.0f));
-        ms.rot_ident[b] = ident ? 1 : 0;
-        if (b > 0 && ms.subtree[b] == 1) {
-          int ci = 0;
-          for (int j = 1; j < b; ++j) ci += ms.subtree[j] == 1 ? 1 : 0;
-          int d = ms.depth[b];
-          if (ci < PF_MAX_CHAINS && d <= PF_MAX_CHAIN_DEPTH) {
-            ms.chain_len[ci] = d;
-            int j = b;
-            for (int kk = d - 1; kk >= 0; --kk) { ms.chain[ci][kk] = j; j = ms.parent[j]; }
-          }
-        }
-      }
-      int nch = 0;
-      for (int j = 1; j < NBD; ++j) nch += ms.subtree[j] == 1 ? 1 : 0;
-      PF_ONE { ms.nchain = nch < PF_MAX_CHAINS ? nch : PF_MAX_CHAINS; }
-      PF_SYNC();
-    }
     if (g.mode == 1) {
       reset_env(sh, m, c, L, B, inj, env, g.step_counter);
       PF_ONE { B.d_episode_length[env] = 0; B.d_reset[env] = 1; }

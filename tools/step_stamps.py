@@ -26,10 +26,19 @@ lib.pf_debug_set_stamps(env._h, stamps.data_ptr())
 g = torch.Generator(device="cuda:0").manual_seed(0)
 acc = torch.zeros(16, dtype=torch.float64, device="cuda:0")
 K = 40
+tot_hist = []           # per-wave totals of the timed steps: the launch ends with its SLOWEST wave (all waves are resident at once)
 for i in range(K + 10):
     env.step(torch.randn(N, env.num_actions, device="cuda:0", generator=g) * 0.5)
     if i >= 10:
         acc += stamps.double().mean(0)
+        per_wave = stamps.double().sum(1)
+        per_wave = per_wave[per_wave > 0]          # lane 0 of a wave writes the row of its first robot only
+        sd = stamps.double()[stamps.double().sum(1) > 0]
+        top = sd[sd.sum(1) >= sd.sum(1).quantile(0.99)]
+        top_acc = top.mean(0) if i == 10 else top_acc + top.mean(0)
+        rs = env.reset_buf.bool()
+        tot_hist.append((per_wave.mean().item(), per_wave.median().item(), per_wave.quantile(0.99).item(), per_wave.max().item(),
+                         stamps.double()[:, 14][stamps.double().sum(1) > 0].max().item(), int(rs.sum())))
 torch.cuda.synchronize()
 names = ["loop/ext bookkeeping", "kinematics (FK+vel)", "inertia+composite+F", "mass matrix+bias", "cholesky", "contact detect",
          "contact rows", "solve rows (M^-1 J^T)", "free vel + limits", "delassus blocks", "PGS 4 iters", "integrate+forces",
@@ -40,3 +49,13 @@ print(f"mean cycles per wave per policy step: {tot:.0f} (s_memtime ticks)")
 for i, n in enumerate(names):
     per = "x4 substeps" if i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12) else ""
     print(f"  [{i:2d}] {n:30s} {m[i]:9.0f}  {100 * m[i] / tot:5.1f} %  {per}")
+
+import numpy as np
+h = np.array(tot_hist)
+print(f"per-wave total ticks over {len(h)} steps: mean {h[:, 0].mean():.0f}, median {h[:, 1].mean():.0f}, p99 {h[:, 2].mean():.0f}, max {h[:, 3].mean():.0f} "
+      f"(slowest wave / mean wave = {h[:, 3].mean() / h[:, 0].mean():.3f}); post_physics max {h[:, 4].mean():.0f}; resets per step {h[:, 5].mean():.0f}")
+
+tm = (top_acc / K).cpu().numpy()
+print("slowest 1 % of the waves, mean ticks per phase (vs all waves):")
+for i, n in enumerate(names):
+    print(f"  [{i:2d}] {n:30s} {tm[i]:9.0f}  ({2 * m[i]:9.0f})")
