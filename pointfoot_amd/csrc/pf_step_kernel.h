@@ -17,6 +17,7 @@
 #define PF_MAXC_QUAD 10
 #define PF_MAX_CHAINS 8
 #define PF_MAX_CHAIN_DEPTH 8
+#include <cmath>
 #include "pf_lump.h"
 #define PF_KSPH 24         /* collision spheres staged per robot (PointFoot instance; the quadruped instance uses 32) */
 #define PF_KSPH_QUAD 32
@@ -280,6 +281,7 @@ struct PfKernel {
     int sph_body[KS], sph_rep[KS];                // body that carries sphere s / body its contact force is reported on
     float sph_pos[KS][3], sph_radius[KS];
     int ncap, npair, cap_s0[KC], cap_s1[KC], pair_a[KP], pair_b[KP];
+    float pair_reach[KP];      // half lengths + radii of the pair's two capsules: midpoints further apart than this + contact_offset cannot touch
     // root-to-leaf chains (one lane walks one chain in forward kinematics) and per-body 'fixed rotation is identity' flags
     int nchain, chain_len[PF_MAX_CHAINS], chain[PF_MAX_CHAINS][PF_MAX_CHAIN_DEPTH], rot_ident[NBD];
   };
@@ -305,7 +307,19 @@ struct PfKernel {
       for (int t = 0; t < 3; ++t) ms.feet_off[f][t] = lump.feet_off[f][t];
     }
     for (int t = 0; t < KC && t < PF_MAX_CAPS; ++t) { ms.cap_s0[t] = gm.cap_s0[t]; ms.cap_s1[t] = gm.cap_s1[t]; }
-    for (int t = 0; t < KP && t < PF_MAX_PAIRS; ++t) { ms.pair_a[t] = gm.pair_a[t]; ms.pair_b[t] = gm.pair_b[t]; }
+    for (int t = 0; t < KP && t < PF_MAX_PAIRS; ++t) {
+      ms.pair_a[t] = gm.pair_a[t]; ms.pair_b[t] = gm.pair_b[t];
+      float reach = 0.0f;
+      if (t < gm.npair) {
+        const int caps[2] = {gm.pair_a[t], gm.pair_b[t]};
+        for (int u = 0; u < 2; ++u) {
+          const float *p0 = gm.sph_pos[gm.cap_s0[caps[u]]], *p1 = gm.sph_pos[gm.cap_s1[caps[u]]];
+          const double dx = (double)p1[0] - p0[0], dy = (double)p1[1] - p0[1], dz = (double)p1[2] - p0[2];
+          reach += (float)(0.5 * std::sqrt(dx * dx + dy * dy + dz * dz)) + gm.sph_radius[gm.cap_s0[caps[u]]];
+        }
+      }
+      ms.pair_reach[t] = reach * 1.0001f + 1e-4f;      // (margin against the rounding of the test below)
+    }
     for (int t = 0; t < PF_MAX_TERM; ++t) ms.term_body[t] = gm.term_body[t];
     for (int t = 0; t < PF_MAX_PEN; ++t) ms.pen_body[t] = gm.pen_body[t];
     ms.nsph = gm.nsph; ms.n_term = gm.n_term; ms.n_pen = gm.n_pen; ms.ncap = gm.ncap; ms.npair = gm.npair;
@@ -734,9 +748,11 @@ struct PfKernel {
     PF_SYNC();
     PF_STAMP(sh, 2);
     // ---- mass matrix (lower triangle; generalised velocity [v_O, w, qd]) + bias + old velocity
-    PF_LANES(e, NV * NV) {
-      int a = e / NV, b = e - a * NV;
-      if (b > a) continue;
+    PF_LANES(e, NV * (NV + 1) / 2) {      // entry e of the packed lower triangle: row a = largest a with a (a + 1) / 2 <= e
+      int a = (int)((pf_sqrt(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      a += ((a + 1) * (a + 2) / 2 <= e) ? 1 : 0;      // (the square root may be an ulp off at the row starts)
+      a -= (a * (a + 1) / 2 > e) ? 1 : 0;
+      const int b = e - a * (a + 1) / 2;
       float v = 0.0f;
       if (a < 6) {
         const float* C = sh.Ic[0];
@@ -872,8 +888,14 @@ struct PfKernel {
       PF_LANES(p, npair) {
         const int ca = m.pair_a[p], cb = m.pair_b[p];
         const int a0 = m.cap_s0[ca], b0 = m.cap_s0[cb];
+        // capsules whose midpoints are further apart than their reach cannot be within contact_offset: the closest-point
+        // computation is skipped (by the whole wavefront when no pair of its robots is near -- the usual case)
+        const float *pa0 = sh.sphc[a0], *pa1 = sh.sphc[m.cap_s1[ca]], *pb0 = sh.sphc[b0], *pb1 = sh.sphc[m.cap_s1[cb]];
+        const float mx = 0.5f * ((pa0[0] + pa1[0]) - (pb0[0] + pb1[0])), my = 0.5f * ((pa0[1] + pa1[1]) - (pb0[1] + pb1[1])), mz = 0.5f * ((pa0[2] + pa1[2]) - (pb0[2] + pb1[2]));
+        const float lim = m.pair_reach[p] + c.contact_offset;
+        if (mx * mx + my * my + mz * mz > lim * lim) { sh.pd[p] = 1e9f; continue; }
         float v[3], c2[3];
-        segment_segment(sh.sphc[a0], sh.sphc[m.cap_s1[ca]], sh.sphc[b0], sh.sphc[m.cap_s1[cb]], v, c2);
+        segment_segment(pa0, pa1, pb0, pb1, v, c2);
         const float len = pf_sqrt(pf_dot3(v, v)), rb = m.sph_radius[b0];
         const float dist = len - m.sph_radius[a0] - rb;
         const bool ok = len > 1e-9f;
