@@ -387,7 +387,8 @@ struct PfKernel {
 
   // ------------------------------------------------------------------ terrain
   // point_foot.py:1100-1112 for one point; exact float32 op order of the reference, no FMA contraction
-  PF_DEV float height_raw(const PfConfig& c, const int16_t* hs, float wx, float wy) {
+  // index of the height sample at the low corner of the cell under (wx, wy) -- _get_heights' clipped integer coordinates (:1062-1068)
+  PF_DEV int height_cell(const PfConfig& c, float wx, float wy) {
 #if !defined(PF_HOST_EMU)
 #pragma clang fp contract(off)
 #endif
@@ -396,7 +397,11 @@ struct PfKernel {
     int ix = (int)fx, iy = (int)fy;
     ix = ix < 0 ? 0 : (ix > c.hf_rows - 2 ? c.hf_rows - 2 : ix);
     iy = iy < 0 ? 0 : (iy > c.hf_cols - 2 ? c.hf_cols - 2 : iy);
-    int h1 = hs[ix * c.hf_cols + iy], h2 = hs[(ix + 1) * c.hf_cols + iy], h3 = hs[ix * c.hf_cols + iy + 1];
+    return ix * c.hf_cols + iy;
+  }
+  PF_DEV float height_raw(const PfConfig& c, const int16_t* hs, float wx, float wy) {
+    const int at = height_cell(c, wx, wy);
+    int h1 = hs[at], h2 = hs[at + c.hf_cols], h3 = hs[at + 1];
     int h = h1 < h2 ? h1 : h2;
     h = h < h3 ? h : h3;
     return (float)h;
@@ -1532,6 +1537,44 @@ struct PfKernel {
     nrm = nrm < 1e-9f ? 1e-9f : nrm;
     qy[2] /= nrm; qy[3] /= nrm;
     float hsum = 0.0f;
+#if !defined(PF_HOST_EMU)
+    if (c.terrain_type != PF_TERRAIN_PLANE) {
+      // Same arithmetic per point as the loop below, in two sweeps: every sample of this lane's points (up to PER of them) is
+      // requested before the first one is used -- one memory round trip for the scan instead of one per point.
+      constexpr int PER = (PF_MAX_HPTS + PF_W - 1) / PF_W;
+      const int16_t* hs = B.d_height_samples;
+      int at[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int j = PF_LANE_ID + u * PF_W;
+        at[u] = -1;
+        if (j < H) {
+          float pl[3] = {c.height_px[j], c.height_py[j], 0.0f}, pw[3];
+          pf_quat_apply(qy, pl, pw);
+          at[u] = height_cell(c, pw[0] + S[LC::root], pw[1] + S[LC::root + 1]);
+        }
+      }
+      int h1[PER], h2[PER], h3[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int a = at[u] < 0 ? 0 : at[u];
+        h1[u] = hs[a]; h2[u] = hs[a + c.hf_cols]; h3[u] = hs[a + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int j = PF_LANE_ID + u * PF_W;
+        if (at[u] >= 0) {
+          int h = h1[u] < h2[u] ? h1[u] : h2[u];
+          h = h < h3[u] ? h : h3[u];
+          const float hv = (float)h * c.vscale;
+          hts[j] = hv;
+          if (B.d_measured_heights) B.d_measured_heights[(size_t)env * H + j] = hv;      // only when a caller asked for the tensor
+          hsum += root_z - hv;
+        }
+      }
+      return PF_WAVE_SUM(hsum);
+    }
+#endif
     PF_LANES(j, H) {
       float hv = 0.0f;
       if (c.terrain_type != PF_TERRAIN_PLANE) {
