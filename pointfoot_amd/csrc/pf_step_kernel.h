@@ -1671,9 +1671,13 @@ struct PfKernel {
     }
     bool time_out = (float)ep > c.max_episode_length;
     bool reset = term || time_out;
-    // :301-318 rewards (uniform; every lane computes the same scalars)
+    // :301-318 rewards: one lane per reward term (the terms are independent; a loop over them pays a scalar load of the term's id, a
+    // branch and the term's LDS reads one after the other, 19 times); the scaled terms are then added up in term order by every lane --
+    // the same sum as the loop's
     float rew = 0.0f;
-    for (int ri = 0; ri < c.num_rewards; ++ri) {
+    float* rterm = &sh.W[0][0];      // (constraint-row storage: physics only)
+    static_assert(NROWS * NVP >= PF_MAX_REWARDS, "reward terms do not fit the aliased row storage");
+    PF_LANES(ri, c.num_rewards) {
       float v = 0.0f;
       switch (c.reward_id[ri]) {
         case PF_REW_LIN_VEL_Z: v = blv[2] * blv[2]; break;
@@ -1704,7 +1708,7 @@ struct PfKernel {
             float first = (air > 0.0f && filt) ? 1.0f : 0.0f;
             air += c.dt;
             acc += (air - 0.5f) * first;
-            if (PF_LANE_ID == 0) { S[LC::last_contacts + f] = contact ? 1.0f : 0.0f; S[LC::feet_air_time + f] = filt ? air * 0.0f : air; }
+            S[LC::last_contacts + f] = contact ? 1.0f : 0.0f; S[LC::feet_air_time + f] = filt ? air * 0.0f : air;      // (this term's lane only)
           }
           float cn = sqrtf(S[LC::commands] * S[LC::commands] + S[LC::commands + 1] * S[LC::commands + 1]);
           v = acc * (cn > 0.1f ? 1.0f : 0.0f);
@@ -1746,9 +1750,11 @@ struct PfKernel {
         default: break;
       }
       float r = v * c.reward_scale[ri];
-      rew += r;
-      if (PF_LANE_ID == 0) S[LC::episode_sums + ri] += r;
+      rterm[ri] = r;
+      S[LC::episode_sums + ri] += r;
     }
+    PF_SYNC();
+    for (int ri = 0; ri < c.num_rewards; ++ri) rew += rterm[ri];
     if (c.only_positive_rewards) rew = fmaxf(rew, 0.0f);
     if (c.termination_scale != 0.0f) {
       float r = ((reset && !time_out) ? 1.0f : 0.0f) * c.termination_scale;
