@@ -94,7 +94,10 @@ enum PfTerrain { PF_TERRAIN_PLANE = 0, PF_TERRAIN_HEIGHTFIELD = 1 }; /* point_fo
 
 /* Collapsed articulated model (what Isaac Gym's load_asset derives from the URDF with
  * collapse_fixed_joints=True; point_foot.py:883-909).  Bodies are in
- * depth-first order, parent[b] < b, a subtree is the contiguous range [b, b+subtree[b]). */
+ * depth-first order, parent[b] < b, a subtree is the contiguous range [b, b+subtree[b]).
+ * pf_create integrates a copy in which bodies behind fixed joints (the feet) are lumped into their parents
+ * (pointfoot_amd/csrc/pf_lump.h: the same rigid-body system, shorter kinematic chains); everything the env reports per body
+ * (contact forces, feet positions, termination / penalised contact indices) keeps the body indices of THIS struct. */
 typedef struct PfModel {
   int32_t nb, nd, nfeet, nsph;
   int32_t parent[PF_MAX_BODIES];
