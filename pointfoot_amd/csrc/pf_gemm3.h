@@ -432,7 +432,8 @@ __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bi
         uint2 p0, p1, p2;
         g3_split4(ra[i], p0, p1, p2);
         uint16_t* d = As + (idx / CA) * RSA + (idx % CA) * 4;
-        *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PLANE_A) = p1; *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = p2;
+        if constexpr ((G3_ABLATE & 4) != 0) { G3_KEEP(p0.x); G3_KEEP(p0.y); G3_KEEP(p1.x); G3_KEEP(p1.y); G3_KEEP(p2.x); G3_KEEP(p2.y); }
+        else { *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PLANE_A) = p1; *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = p2; }
         csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w;
       }
 #pragma unroll
@@ -441,7 +442,8 @@ __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bi
         uint2 p0, p1, p2;
         g3_split4(rb[i], p0, p1, p2);
         uint16_t* d = Bs + (idx / CB) * RSB + (idx % CB) * 4;
-        *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PLANE_B) = p1; *reinterpret_cast<uint2*>(d + 2 * PLANE_B) = p2;
+        if constexpr ((G3_ABLATE & 4) != 0) { G3_KEEP(p0.x); G3_KEEP(p0.y); G3_KEEP(p1.x); G3_KEEP(p1.y); G3_KEEP(p2.x); G3_KEEP(p2.y); }
+        else { *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PLANE_B) = p1; *reinterpret_cast<uint2*>(d + 2 * PLANE_B) = p2; }
       }
     };
     f32x16 acc[TM][TN];
@@ -480,6 +482,11 @@ __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bi
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
+            if constexpr ((G3_ABLATE & 1) != 0) {
+#pragma unroll
+              for (int p = 0; p < 3; ++p) { G3_KEEP(a[i][p]); G3_KEEP(b[j][p]); }
+              continue;
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);

@@ -12,7 +12,9 @@ if [ "$1" = build ]; then
   done
   wait
 else
-  for shape in "0 24576 256 512 1 0" "0 24576 256 512 1 1" "1 24576 512 256 1 1" "0 4096 4096 4096 0 0"; do
+  SHAPES=${SHAPES:-"0 24576 256 512 1 0|0 24576 256 512 1 1|1 24576 512 256 1 1|0 4096 4096 4096 0 0|2 256 512 24576 0 0"}
+  IFS='|' read -ra LIST <<< "$SHAPES"
+  for shape in "${LIST[@]}"; do
     for m in $MASKS; do tools/_build/gemm_ablate_$m $shape; done
   done
 fi
