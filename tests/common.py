@@ -51,6 +51,8 @@ def emu_lib():
     lib.pfe_step.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfConfig), C.POINTER(_abi.PfLayout),
                              C.POINTER(_abi.PfBuffers), C.c_void_p, C.c_longlong, C.POINTER(_abi.PfInject), C.c_int, C.c_void_p]
     lib.pfe_layout.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfConfig), C.POINTER(_abi.PfLayout)]
+    lib.pfe_lump.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfModel), C.c_void_p]
+    lib.pfe_lump.restype = None
     return lib
 
 

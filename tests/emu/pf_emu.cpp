@@ -34,3 +34,5 @@ extern "C" int pfe_step(const PfModel* model, const PfConfig* cfg, const PfLayou
   return 0;
 }
 extern "C" int pfe_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out) { return pf_compute_layout(model, cfg, out); }
+// the model the product integrates (fixed-joint bodies lumped into their parents) and its reporting tables, for the unit test of pf_lump.h
+extern "C" void pfe_lump(const PfModel* model, PfModel* out, PfLump* map) { pf_lump_model(model, out, map); }

@@ -298,3 +298,62 @@ def test_emu_matches_oracle_on_quadruped_self_contacts():
         np.testing.assert_array_equal(a.contact_set, b.contact_set)
         np.testing.assert_allclose(b.state, a.state, atol=5e-3, rtol=1e-3)
         b.state[:] = a.state
+
+
+@pytest.mark.parametrize("task", ["flat", "anymal_c_flat"])
+def test_lumped_model_is_the_same_rigid_body_system(task):
+    """pf_lump.h (what pf_create hands the step kernel): bodies behind fixed joints -- the feet -- are merged into their parents.  For random
+    joint angles the lumped tree must put every collision sphere and every foot origin where the full tree puts them, and carry the same total
+    mass, centre of mass and rotational inertia about the base origin (computed here in float64 from both models)."""
+    import ctypes as C
+    cfg = common.make_cfg(task, 1)
+    sim = common.HostSim(cfg, 1)
+    full = sim.model
+    lumped = type(full)()
+    class Lump(C.Structure):
+        _fields_ = [("sph_rep", C.c_int32 * common._abi.PF_MAX_SPHERES), ("feet_dyn", C.c_int32 * common._abi.PF_MAX_FEET),
+                    ("feet_off", (C.c_float * 3) * common._abi.PF_MAX_FEET)]
+    lump = Lump()
+    common.emu_lib().pfe_lump(C.byref(full), C.byref(lumped), C.byref(lump))
+    nfixed = sum(1 for i in range(1, full.nb) if full.dof_of_body[i] < 0)
+    assert nfixed == full.nfeet and lumped.nb == full.nb - nfixed and lumped.nd == full.nd
+
+    def rodrigues(a, th):
+        a = np.asarray(a, np.float64); K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+    def fk(m, q):      # world frame of every body (base at the origin, identity)
+        R, r = [np.eye(3)], [np.zeros(3)]
+        for i in range(1, m.nb):
+            p = m.parent[i]
+            Rj = R[p] @ np.array(m.joint_rot[i], np.float64).reshape(3, 3)
+            k = m.dof_of_body[i]
+            if k >= 0:
+                Rj = Rj @ rodrigues(m.joint_axis[i], q[k])
+            R.append(Rj); r.append(r[p] + R[p] @ np.array(m.joint_pos[i], np.float64))
+        return R, r
+
+    def mass_props(m, R, r):      # total mass, first moment, inertia about the origin
+        M, h, I = 0.0, np.zeros(3), np.zeros((3, 3))
+        for i in range(m.nb):
+            mi = float(m.mass[i]); c = r[i] + R[i] @ np.array(m.com[i], np.float64)
+            a = m.inertia[i]; Il = np.array([[a[0], a[3], a[4]], [a[3], a[1], a[5]], [a[4], a[5], a[2]]], np.float64)
+            M += mi; h += mi * c; I += R[i] @ Il @ R[i].T + mi * (c @ c * np.eye(3) - np.outer(c, c))
+        return M, h, I
+
+    rs = np.random.RandomState(3)
+    for _ in range(5):
+        q = rs.uniform(-1.0, 1.0, full.nd)
+        Rf, rf = fk(full, q); Rl, rl = fk(lumped, q)
+        for s in range(full.nsph):
+            pf_ = rf[full.sph_body[s]] + Rf[full.sph_body[s]] @ np.array(full.sph_pos[s], np.float64)
+            pl_ = rl[lumped.sph_body[s]] + Rl[lumped.sph_body[s]] @ np.array(lumped.sph_pos[s], np.float64)
+            np.testing.assert_allclose(pl_, pf_, atol=2e-6)
+            assert lump.sph_rep[s] == full.sph_body[s]
+        for f in range(full.nfeet):
+            b = lump.feet_dyn[f]
+            np.testing.assert_allclose(rl[b] + Rl[b] @ np.array(lump.feet_off[f], np.float64), rf[full.feet_body[f]], atol=2e-6)
+        Mf, hf, If = mass_props(full, Rf, rf); Ml, hl, Il = mass_props(lumped, Rl, rl)
+        assert abs(Mf - Ml) < 1e-5 * Mf
+        np.testing.assert_allclose(hl, hf, atol=1e-5 * Mf)
+        np.testing.assert_allclose(Il, If, atol=2e-5 * np.abs(If).max())
