@@ -9,15 +9,96 @@ policy) and resident in HBM before the timed region.  value = N_gpus * 4096 * 24
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks ITSELF (`self_launch`): the parent never
+imports torch, never touches the GPU, starts `python -m torch.distributed.run` as a child process, relays rank 0's one JSON line
+and exits with the child's code.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--num_envs", type=int, default=4096)
+    p.add_argument("--task", type=str, default="pointfoot_rough")
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_alt", action="store_true", help="skip the second timed loop on the fp32 MFMA kernels")
+    p.add_argument("--gemm", choices=["auto", "fp32", "bf16x6"], default="auto",
+                   help="dense-layer arithmetic: fp32 MFMA, fp32 by exact 3-way bf16 split on the bf16 MFMA, or by network width (default)")
+    p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    p.add_argument("--single_device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
+    p.add_argument("--self_launch", action="store_true",
+                   help="start the ranks through torch.distributed.run from a parent that never touches the GPU even when --gpus 1 "
+                        "(always done for --gpus N > 1 outside torchrun)")
+    p.add_argument("--master_port", type=int, default=0, help="rendezvous port of the self-launched job (0: pick a free one)")
+    return p.parse_args(argv)
+
+
+def under_torchrun(env=None):
+    env = os.environ if env is None else env
+    return "WORLD_SIZE" in env and "RANK" in env
+
+
+def needs_self_launch(a, env=None):
+    """True in the parent of a multi-rank run: --gpus N > 1 (or --self_launch) and no torchrun environment yet."""
+    return (a.gpus > 1 or a.self_launch) and not under_torchrun(env)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch_command(a, argv, port):
+    """The child a parent starts: one process per GPU of ONE node over RCCL -- exactly the command line the driver uses."""
+    child_args = [x for x in argv if x != "--self_launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child_args
+
+
+def self_launch(a, argv):
+    """Parent of an N-rank run.  Nothing here imports torch or makes a HIP call: the ranks are fresh child processes (never an
+    exec of a process that has initialised the GPU).  stdout of the job = the ONE JSON line rank 0 prints; everything else the
+    ranks write (stderr, banners) passes through on stderr."""
+    assert "torch" not in sys.modules, "bench.py parent imported torch before starting its ranks"
+    port = a.master_port or free_port()
+    cmd = self_launch_command(a, argv, port)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("[bench] starting ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, cwd=os.getcwd())
+    line = None
+    for ln in proc.stdout:
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(s, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("[bench] the ranks exited 0 without a result line", file=sys.stderr, flush=True)
+        rc = 1
+    return rc
+
+
+if __name__ == "__main__" and needs_self_launch(parse()):
+    sys.exit(self_launch(parse(), sys.argv[1:]))
 
 import numpy as np
 import torch
@@ -45,22 +126,6 @@ def step_traffic(kernel_prefix, task, num_envs):
         except (OSError, KeyError, ValueError):
             continue
     return None, None
-
-
-def parse():
-    p = argparse.ArgumentParser()
-    p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--num_envs", type=int, default=NUM_ENVS)
-    p.add_argument("--task", type=str, default="pointfoot_rough")
-    p.add_argument("--no_cpu_baseline", action="store_true")
-    p.add_argument("--no_alt", action="store_true", help="skip the second timed loop on the fp32 MFMA kernels")
-    p.add_argument("--gemm", choices=["auto", "fp32", "bf16x6"], default="auto",
-                   help="dense-layer arithmetic: fp32 MFMA, fp32 by exact 3-way bf16 split on the bf16 MFMA, or by network width (default)")
-    p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
-    p.add_argument("--single_device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
-    return p.parse_args()
 
 
 def make(task, num_envs, device):
@@ -191,7 +256,8 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(a.backend)
+            from pointfoot_amd import dp
+            dp.init_process_group(a.backend, local)       # nccl: bound to cuda:<local> (device_id)
             dist.barrier()
         finally:
             sys.stdout.flush()
@@ -304,7 +370,10 @@ def main():
         finally:
             del os.environ["PF_PPO_GEMM"]
     lockstep = None
+    dp_backend = None
     if dist_on:
+        from pointfoot_amd import dp
+        dp_backend = dp.backend_name()
         # every rank must hold the same policy and have taken the same learning-rate decisions: compare a checksum of the
         # flat parameter buffer (as exact integers: the float32 bit patterns summed in int64) and the LR scalar across ranks
         alg = runner.alg
@@ -345,11 +414,13 @@ def main():
                                    f"minibatches of {a.num_envs * T // runner.alg.num_mini_batches}, actor {dims(ac.actor_dims)} / critic {dims(ac.critic_dims)} (ELU), fp32"
                                    + (" (dense layers: every fp32 operand split exactly into 3 bf16 terms, 6 of the 9 partial products on the bf16 MFMA, fp32 accumulation; dropped terms < 2^-23 relative)" if x6 else " (fp32 MFMA)")
                                    + (", ANYdrive actuator-network LSTM in the step kernel" if anymal else ""),
-                       "parallelism": f"dp{n_gpus} (env shards, RCCL gradient all-reduce)" if n_gpus > 1 else "single GPU",
+                       "parallelism": (f"dp{n_gpus} (env shards, gradient all-reduce over "
+                                       + ("RCCL/xGMI" if dp_backend == "nccl" else f"{dp_backend} -- a rehearsal backend, NOT RCCL") + ")") if n_gpus > 1 else "single GPU",
                        "finite": finite},
             "ranks_in_lockstep": lockstep,
-            "collectives": ((f"{a.backend} group of ONE rank, every collective of the N>1 path issued (PF_DP_SINGLE_RANK_COLLECTIVES=1 rehearsal)" if rehearse1
-                             else f"{a.backend}, {world} ranks") if dist_on else None),
+            # named from the process group itself (dp.backend_name: "nccl" = RCCL), not from the flag
+            "collectives": ((f"{dp_backend}, group of ONE rank with every collective of the N>1 path issued (PF_DP_SINGLE_RANK_COLLECTIVES=1 rehearsal)" if rehearse1
+                             else f"{dp_backend}, {world} ranks") if dist_on else None),
             "alt_fp32_mfma": alt,
             "roofline": {"kernel": kern + " (fused env step)", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,

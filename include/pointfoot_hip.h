@@ -300,6 +300,8 @@ int pf_measure_heights(PfEnv* env, void* stream);
  * replaces rsl_rl v1.0.2 (un-vendored dependency; setup.py:13): OnPolicyRunner.learn's inner calls
  * alg.act / alg.process_env_step / alg.compute_returns / alg.update (call site train.py:44). */
 #define PPO_MAX_LAYERS 4       /* hidden layers + 1 output */
+#define PPO_EP_RING 100        /* rsl_rl OnPolicyRunner: rewbuffer = deque(maxlen=100) */
+#define PPO_EP_RING_INTS (4 + 4 * PPO_EP_RING)
 
 typedef struct PpoConfig {
   int32_t num_envs, num_steps;            /* N, T (num_steps_per_env, pointfoot_rough_config.py:246) */
@@ -343,6 +345,12 @@ typedef struct PpoBuffers {
   float* d_ep_return;  /* [N] running undiscounted return of the current episode (runner statistics), or NULL */
   float* d_ep_length;  /* [N] running length of the current episode, or NULL */
   float* d_ep_stats;   /* [4]: sum of finished-episode returns, sum of their lengths, count (since the host last zeroed it) */
+  float* d_ep_fin;     /* [2,T,N] or NULL: undiscounted return and length of the episode that ended at (t, env); written where done */
+  int32_t* d_ep_ring;  /* [PPO_EP_RING_INTS] or NULL: the last PPO_EP_RING finished episodes in (step, env) order -- what rsl_rl's
+                          OnPolicyRunner keeps in rewbuffer / lenbuffer = deque(maxlen=100) (call site legged_gym/scripts/train.py:44).
+                          Header {next slot, entries held, episodes seen, policy steps seen}; then per slot {return (float bits),
+                          length (float bits), policy-step index, episode sequence number}.  Appended to once per rollout by
+                          ppo_compute_returns from d_dones / d_ep_fin; the host zeroes it at start and only ever reads it. */
   float* d_scalars;    /* [16]: 0 lr, 1 mean_kl, 2 grad_norm, 3 value_loss_sum, 4 surrogate_loss_sum,
                           5 adam_step, 6 adv_mean, 7 adv_std, 8 kl_sum_local, 9 n_updates */
 } PpoBuffers;
@@ -392,6 +400,9 @@ int ppo_minibatch_backward(PpoAlg* alg, int32_t minibatch_index, void* stream);
  * parameters); returns 0, -1 on a bad config.  Needs the paired execution mode (actor and critic of equal depth). */
 int ppo_minibatch_backward_part(PpoAlg* alg, int32_t minibatch_index, int32_t part, void* stream);
 int32_t ppo_grad_groups(const PpoConfig* cfg, int64_t* ranges4);
+/* 1 when THIS handle can run ppo_minibatch_backward_part (paired execution: equal depth, fused heads, not switched off by
+ * PF_PPO_PAIRED=0 / PF_PPO_FUSED_HEADS=0), else 0: the host then keeps the whole-pass call and one blocking all-reduce. */
+int32_t ppo_supports_parts(const PpoAlg* alg);
 /* grad-norm clip (over the possibly all-reduced d_grads, divided by world_size) + Adam step */
 int ppo_minibatch_apply(PpoAlg* alg, void* stream);
 

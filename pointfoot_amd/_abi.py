@@ -19,6 +19,8 @@ PF_MAX_CAPS = 16
 PF_MAX_PAIRS = 64
 PF_CSET_WORDS = 4
 PPO_MAX_LAYERS = 4
+PPO_EP_RING = 100
+PPO_EP_RING_INTS = 4 + 4 * PPO_EP_RING
 PF_STATS_FLOATS = PF_MAX_REWARDS + 4
 PF_STAT_CAP_HITS = PF_MAX_REWARDS + 1
 PF_STAT_CAP_DROPPED = PF_MAX_REWARDS + 2
@@ -131,7 +133,8 @@ class PpoBuffers(C.Structure):
     _fields_ = [(n, vp) for n in (
         "d_params", "d_grads", "d_adam_m", "d_adam_v", "d_obs", "d_critic_obs", "d_actions", "d_rewards", "d_dones",
         "d_values", "d_returns", "d_advantages", "d_log_prob", "d_mu", "d_sigma", "d_perm", "d_workspace")] + [
-        ("workspace_floats", C.c_int64), ("d_ep_return", vp), ("d_ep_length", vp), ("d_ep_stats", vp), ("d_scalars", vp)]
+        ("workspace_floats", C.c_int64), ("d_ep_return", vp), ("d_ep_length", vp), ("d_ep_stats", vp), ("d_ep_fin", vp), ("d_ep_ring", vp),
+        ("d_scalars", vp)]
 
 
 _LIB = None
@@ -207,6 +210,8 @@ def _bind_ppo(lib):
     lib.ppo_minibatch_backward_part.restype = i32
     lib.ppo_grad_groups.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.ppo_grad_groups.restype = i32
+    lib.ppo_supports_parts.argtypes = [vp]
+    lib.ppo_supports_parts.restype = i32
     for fn in ("ppo_bind_buffers", "ppo_act", "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns",
                "ppo_normalize_advantages", "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_apply"):
         getattr(lib, fn).restype = i32
@@ -223,4 +228,4 @@ EXPORTED_SYMBOLS = [
     "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations",
     "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act",
     "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",
-    "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_backward_part", "ppo_grad_groups", "ppo_minibatch_apply"]
+    "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_backward_part", "ppo_grad_groups", "ppo_supports_parts", "ppo_minibatch_apply"]

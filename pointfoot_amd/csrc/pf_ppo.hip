@@ -180,18 +180,62 @@ __global__ __launch_bounds__(256) void k_act_heads(int N, int A, int O, int P, i
 // PPO.process_env_step: bootstrap on time-outs, store reward / done
 __global__ void k_process(int N, float gamma, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
                           const uint8_t* __restrict__ time_outs, const float* __restrict__ s_val, float* __restrict__ s_rew,
-                          float* __restrict__ s_done, float* __restrict__ ep_ret, float* __restrict__ ep_len, float* __restrict__ ep_stats) {
+                          float* __restrict__ s_done, float* __restrict__ ep_ret, float* __restrict__ ep_len, float* __restrict__ ep_stats,
+                          float* __restrict__ fin_ret, float* __restrict__ fin_len) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   float r = rew[i];
   bool done = dones[i] != 0;
   if (ep_ret) {     // OnPolicyRunner bookkeeping (cur_reward_sum / cur_episode_length / rewbuffer), kept on the device
     float cr = ep_ret[i] + r, cl = ep_len[i] + 1.0f;
-    if (done) { atomicAdd(ep_stats, cr); atomicAdd(ep_stats + 1, cl); atomicAdd(ep_stats + 2, 1.0f); cr = 0.0f; cl = 0.0f; }
+    if (done) {
+      atomicAdd(ep_stats, cr); atomicAdd(ep_stats + 1, cl); atomicAdd(ep_stats + 2, 1.0f);
+      if (fin_ret) { fin_ret[i] = cr; fin_len[i] = cl; }      // picked up by k_episode_ring at the end of the rollout
+      cr = 0.0f; cl = 0.0f;
+    }
     ep_ret[i] = cr; ep_len[i] = cl;
   }
   if (time_outs) r += gamma * (s_val[i] * (time_outs[i] ? 1.0f : 0.0f));
   s_rew[i] = r; s_done[i] = done ? 1.0f : 0.0f;
+}
+
+// rsl_rl OnPolicyRunner.learn: `rewbuffer.extend(cur_reward_sum[new_ids])`, `lenbuffer.extend(cur_episode_length[new_ids])` with
+// deque(maxlen=100) -- the last 100 FINISHED EPISODES in (step, env index) order.  One launch per rollout, one workgroup: a scan over
+// the rollout's T*N done flags in that order appends the finished episodes to a ring of PPO_EP_RING entries in device memory; no
+// host synchronisation, the runner reads the ring only when it logs.
+__global__ void __launch_bounds__(1024) k_episode_ring(int N, int T, const float* __restrict__ s_done, const float* __restrict__ fin,
+                                                       int* __restrict__ ring) {
+  __shared__ int cnt[1024];
+  const int tid = threadIdx.x;
+  const size_t n = (size_t)N * T, per = (n + 1023) / 1024;
+  const size_t lo = (size_t)tid * per < n ? (size_t)tid * per : n, hi = lo + per < n ? lo + per : n;
+  int c = 0;
+  for (size_t i = lo; i < hi; ++i) c += s_done[i] != 0.0f;
+  cnt[tid] = c;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    int v = tid >= d ? cnt[tid - d] : 0;
+    __syncthreads();
+    cnt[tid] += v;
+    __syncthreads();
+  }
+  const int tot = cnt[1023];
+  int p = cnt[tid] - c;
+  const int head = ring[0], count = ring[1], seq = ring[2], step0 = ring[3];
+  __syncthreads();
+  for (size_t i = lo; i < hi; ++i) {
+    if (s_done[i] != 0.0f) {
+      if (p >= tot - PPO_EP_RING) {       // of more than PPO_EP_RING episodes in one rollout only the last ones can stay
+        int* e = ring + 4 + 4 * ((head + p) % PPO_EP_RING);
+        e[0] = __float_as_int(fin[i]); e[1] = __float_as_int(fin[n + i]); e[2] = step0 + (int)(i / N); e[3] = seq + p;
+      }
+      ++p;
+    }
+  }
+  if (tid == 0) {
+    ring[0] = (head + tot) % PPO_EP_RING; ring[1] = count + tot < PPO_EP_RING ? count + tot : PPO_EP_RING;
+    ring[2] = seq + tot; ring[3] = step0 + T;
+  }
 }
 
 // RolloutStorage.compute_returns: GAE reverse scan, one thread per env; advantages = returns - values
@@ -1437,7 +1481,8 @@ int ppo_process_env_step(PpoAlg* a, int32_t t, const float* d_rew, const uint8_t
   size_t tn = (size_t)t * c.num_envs;
   hipLaunchKernelGGL(k_process, dim3((c.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, c.num_envs, c.gamma, d_rew, d_dones,
                      d_time_outs, a->b.d_values + tn, a->b.d_rewards + tn, a->b.d_dones + tn,
-                     a->b.d_ep_stats ? a->b.d_ep_return : nullptr, a->b.d_ep_length, a->b.d_ep_stats);
+                     a->b.d_ep_stats ? a->b.d_ep_return : nullptr, a->b.d_ep_length, a->b.d_ep_stats,
+                     a->b.d_ep_fin ? a->b.d_ep_fin + tn : nullptr, a->b.d_ep_fin ? a->b.d_ep_fin + (size_t)c.num_steps * c.num_envs + tn : nullptr);
   PPO_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -1457,6 +1502,8 @@ int ppo_compute_returns(PpoAlg* a, const float* d_last_critic_obs, void* stream)
   size_t n = (size_t)N * T;
   hipLaunchKernelGGL(k_moments1, dim3(RED_BLOCKS), dim3(256), 0, s, n, a->b.d_advantages, ws + a->w_partial);
   hipLaunchKernelGGL(k_moments2, dim3(1), dim3(64), 0, s, RED_BLOCKS, n, ws + a->w_partial, a->b.d_scalars);
+  if (a->b.d_ep_ring && a->b.d_ep_fin && a->b.d_ep_stats)      // the runner's deque(maxlen=100) of finished episodes, on the device
+    hipLaunchKernelGGL(k_episode_ring, dim3(1), dim3(1024), 0, s, N, T, a->b.d_dones, a->b.d_ep_fin, a->b.d_ep_ring);
   PPO_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -1583,6 +1630,8 @@ int ppo_minibatch_backward_part(PpoAlg* a, int32_t mb, int32_t part, void* strea
   if (part != 0 && part != 1) { pf_set_error("ppo_minibatch_backward_part: part must be 0 or 1"); return 1; }
   return minibatch_backward(a, mb, stream, part);
 }
+
+int32_t ppo_supports_parts(const PpoAlg* a) { return a && a->fused_heads && a->paired ? 1 : 0; }
 
 int32_t ppo_grad_groups(const PpoConfig* cfg, int64_t* ranges) {
   if (ppo_check_cfg(cfg) || !ranges) return -1;

@@ -107,8 +107,61 @@ def reduce_episode_infos(ep_infos, device):
     return out
 
 
+def merge_episode_rings(ring, maxlen=100):
+    """The device-side ring of finished episodes (PpoBuffers.d_ep_ring: header {next slot, held, seen, steps}, then per slot
+    {return bits, length bits, policy-step index, sequence number}) -> (returns, lengths) as rsl_rl's OnPolicyRunner would hold
+    them in `rewbuffer` / `lenbuffer = deque(maxlen=100)`: the last 100 FINISHED EPISODES, oldest first.  Under torch.distributed
+    the ranks' rings are concatenated: ONE process with all the envs appends the episodes of a step in global env order, i.e.
+    ordered by (policy step, rank, position inside the rank); the last 100 of that sequence are among the ranks' own last 100s.
+    Collective when collectives are on: every rank must call it."""
+    import torch
+    rank, ws = world()
+    rings = [ring]
+    if collectives_on():
+        rings = [torch.empty_like(ring) for _ in range(ws)]
+        dist.all_gather(rings, ring.contiguous())
+    entries = []
+    for r, t in enumerate(rings):
+        host = t.detach().cpu()
+        held = int(host[1])
+        body = host[4:].view(-1, 4)
+        vals = body[:, :2].contiguous().view(torch.float32)
+        head = int(host[0])
+        for k in range(held):              # oldest first: the `held` slots that end just before `head`
+            slot = (head - held + k) % body.shape[0]
+            entries.append((int(body[slot, 2]), r, int(body[slot, 3]), float(vals[slot, 0]), float(vals[slot, 1])))
+    entries.sort(key=lambda e: e[:3])
+    entries = entries[-maxlen:]
+    return [e[3] for e in entries], [e[4] for e in entries]
+
+
+def init_process_group(backend="nccl", local_rank=None):
+    """`dist.init_process_group` for one process per GPU.  On the nccl (= RCCL) backend the process group is BOUND to this
+    rank's device (`device_id`): RCCL then creates its communicator eagerly on that GPU instead of guessing the device at the
+    first collective ("can cause a hang if rank to GPU mapping is heterogeneous"), and `barrier()` knows which device to use.
+    Returns (rank, world_size)."""
+    import torch
+    if dist.is_initialized():
+        return world()
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        dist.init_process_group(backend)
+    return world()
+
+
+def backend_name():
+    """the collective library the gradient all-reduce really goes through ("nccl" = RCCL on ROCm), or None"""
+    if dist.is_available() and dist.is_initialized():
+        return str(dist.get_backend())
+    return None
+
+
 def init_from_env(backend="nccl"):
     """torchrun-style environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
-        dist.init_process_group(backend)
+        init_process_group(backend)
     return world()

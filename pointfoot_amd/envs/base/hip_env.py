@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from pointfoot_amd import _abi
+from pointfoot_amd import _abi, dp
 from pointfoot_amd.envs.pointfoot import _native
 from pointfoot_amd.utils.terrain import Terrain
 
@@ -93,10 +93,9 @@ class HipEnv:
         self.num_actions = cfg.env.num_actions
         # multi-GPU sharding: rank r owns global envs [r*N, (r+1)*N)  (SURVEY §8e).  Rank / world size come from the process
         # group -- the same source PPO and the runner use -- so env shards and the gradient all-reduce cannot disagree.
-        from pointfoot_amd.rsl_rl import dp
         self.rank, self.world_size = dp.world() if getattr(cfg, "shard_envs", True) else (0, 1)
         if getattr(cfg, "shard_envs", True) and self.world_size == 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call pointfoot_amd.rsl_rl.dp.init_from_env() "
+            raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call pointfoot_amd.dp.init_from_env() "
                                "before creating the env (or set cfg.shard_envs = False for independent replicas)")
         self.extras = {}
         self.viewer = None
@@ -215,21 +214,19 @@ class HipEnv:
             _abi.check(self._lib.pf_reset_idx(self._h, mask.data_ptr(), self.common_step_counter, None, self._stream()), self._lib)
         self._fill_extras()
 
-    def update_command_curriculum(self, env_ids=None):
+    def update_command_curriculum(self, env_ids=None, _totals=None):
         """reference :638-650 (legged_robot.py:303-315): widen the lin_vel_x command range by 0.5 m/s when the mean
         tracking reward of the envs that were just reset exceeds 80 % of its maximum.  `env_ids` is implied: the mean
-        is taken from the step's reset statistics (sum of episode_sums over the reset envs / their count)."""
+        is taken from the step's reset statistics (sum of episode_sums over the reset envs / their count).
+        A LOCAL method, like the reference's: it never issues a collective (a play / eval script may call it on one rank).
+        The training step passes the statistics summed over all ranks in `_totals` (`_maybe_update_command_curriculum`)."""
         if "tracking_lin_vel" not in self._sum_names:
             return
-        i = self._sum_names.index("tracking_lin_vel")
-        stats = self._reset_stats
-        pair = torch.stack([stats[i], stats[_abi.PF_MAX_REWARDS]])
-        from pointfoot_amd.rsl_rl import dp
-        if dp.collectives_on():
-            # every rank must take the same decision (the command range is one number for the whole job): sums and counts of
-            # all shards, i.e. the mean one process with all the envs would see.  Once per max_episode_length steps.
-            pair = dp.allreduce_sum(pair.clone())
-        tot, cnt = (float(v) for v in pair.tolist())         # host sync, once per max_episode_length steps
+        if _totals is None:
+            i = self._sum_names.index("tracking_lin_vel")
+            stats = self._reset_stats
+            _totals = torch.stack([stats[i], stats[_abi.PF_MAX_REWARDS]]).tolist()      # host sync
+        tot, cnt = (float(v) for v in _totals)
         if cnt <= 0:
             return
         mean_sum = tot / cnt
@@ -245,10 +242,20 @@ class HipEnv:
     def _maybe_update_command_curriculum(self):
         """reference :264-266: only on steps where common_step_counter % max_episode_length == 0 (the maximum command is
         common to all envs).  In-kernel resets of that step have already drawn from the old range: the new range
-        applies from the next resampling on (one step later than the reference)."""
+        applies from the next resampling on (one step later than the reference).
+        COLLECTIVE under torch.distributed: every rank steps in lockstep (same counter, same config), and the command range is
+        one number for the whole job, so the decision is taken on the sums and counts of ALL shards -- the mean one process
+        with all the envs would see.  One small all-reduce + host sync per max_episode_length steps."""
         if self.cfg.commands.curriculum and self.init_done and \
                 self.common_step_counter % int(self.max_episode_length) == 0:
-            self.update_command_curriculum()
+            if "tracking_lin_vel" not in self._sum_names:
+                return
+            i = self._sum_names.index("tracking_lin_vel")
+            stats = self._reset_stats
+            pair = torch.stack([stats[i], stats[_abi.PF_MAX_REWARDS]])
+            if dp.collectives_on():
+                pair = dp.allreduce_sum(pair.clone())
+            self.update_command_curriculum(_totals=pair.tolist())
 
     def compute_observations(self):
         _abi.check(self._lib.pf_compute_observations(self._h, self.common_step_counter, None, self._stream()), self._lib)

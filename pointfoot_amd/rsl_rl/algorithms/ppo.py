@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 from pointfoot_amd import _abi
-from pointfoot_amd.rsl_rl import dp
+from pointfoot_amd import dp
 from pointfoot_amd.rsl_rl.storage import RolloutStorage
 
 SC_LR, SC_KL, SC_GNORM, SC_VLOSS, SC_SLOSS, SC_STEP = 0, 1, 2, 3, 4, 5
@@ -109,13 +109,19 @@ class PPO:
         b.d_workspace, b.workspace_floats, b.d_scalars = _ptr(self.workspace), ws, _ptr(self.scalars)
         self.ep_return, self.ep_length, self.ep_stats = z(num_envs), z(num_envs), z(4)
         b.d_ep_return, b.d_ep_length, b.d_ep_stats = _ptr(self.ep_return), _ptr(self.ep_length), _ptr(self.ep_stats)
+        # the runner's deque(maxlen=100) of finished episodes, kept on the device (filled once per rollout by ppo_compute_returns)
+        self.ep_fin = z(2 * num_transitions_per_env * num_envs)
+        self.ep_ring = z(_abi.PPO_EP_RING_INTS, torch.int32)
+        b.d_ep_fin, b.d_ep_ring = _ptr(self.ep_fin), _ptr(self.ep_ring)
         self._bufs = b
         _abi.check(lib.ppo_bind_buffers(self._h, C.byref(b)), lib)
         self._actions = torch.zeros(num_envs, c.num_actions, device=dev)
         # multi-GPU: the gradient buffer as two contiguous ranges in the order the backward pass finishes them
         rng = (C.c_int64 * 4)()
         self._grad_groups = None
-        if lib.ppo_grad_groups(C.byref(c), rng) == 0 and c.n_actor_layers == c.n_critic_layers:
+        # the handle itself says whether it can cut the backward pass (paired execution; PF_PPO_PAIRED=0 / PF_PPO_FUSED_HEADS=0
+        # switch it off): without it update() keeps ppo_minibatch_backward + one blocking all-reduce
+        if lib.ppo_supports_parts(self._h) == 1 and lib.ppo_grad_groups(C.byref(c), rng) == 0:
             e0, en, l0, ln = (int(v) for v in rng)
             assert l0 == 0 and e0 == ln and e0 + en == P + 4
             self._grad_groups = (self.grads[e0:e0 + en], self.grads[l0:l0 + ln])

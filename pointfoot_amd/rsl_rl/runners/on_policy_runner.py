@@ -13,7 +13,7 @@ from collections import deque
 import torch
 import torch.distributed as dist
 
-from pointfoot_amd.rsl_rl import dp
+from pointfoot_amd import dp
 from pointfoot_amd.rsl_rl.algorithms import PPO
 from pointfoot_amd.rsl_rl.modules import ActorCritic
 
@@ -50,6 +50,9 @@ class OnPolicyRunner:
         self.log_interval = int(self.cfg.get("log_interval", 1))
         N, dev = self.env.num_envs, self.device
         self._ep_stats = self.alg.ep_stats          # [sum return, sum length, count] of finished episodes since the last log
+        # rsl_rl v1.0.2: the returns / lengths of the last 100 FINISHED EPISODES (Train/mean_reward, Train/mean_episode_length).
+        # They are collected on the device (PpoBuffers.d_ep_ring, filled once per rollout without a host sync) and copied into
+        # these deques when an iteration is logged.
         self.rewbuffer = deque(maxlen=100)
         self.lenbuffer = deque(maxlen=100)
         _, _ = self.env.reset()
@@ -103,6 +106,7 @@ class OnPolicyRunner:
                 ep_means = dp.reduce_episode_infos(ep_infos, self.device)
                 ep_totals = dp.allreduce_sum(self._ep_stats.clone()).tolist()
                 self._ep_stats.zero_()
+                self.refresh_episode_buffers()
                 if self.rank == 0:
                     self.log(locals())
             if self.log_dir is not None and self.rank == 0 and it % self.save_interval == 0:
@@ -112,15 +116,17 @@ class OnPolicyRunner:
         if self.log_dir is not None and self.rank == 0:
             self.save(os.path.join(self.log_dir, 'model_{}.pt'.format(self.current_learning_iteration)))
 
+    def refresh_episode_buffers(self):
+        """rewbuffer / lenbuffer <- the last 100 finished episodes of ALL env shards (a collective under torch.distributed)"""
+        rets, lens = dp.merge_episode_rings(self.alg.ep_ring, maxlen=self.rewbuffer.maxlen)
+        self.rewbuffer.clear(); self.rewbuffer.extend(rets)
+        self.lenbuffer.clear(); self.lenbuffer.extend(lens)
+
     def log(self, locs, width=80, pad=35):
         n_total = self.num_steps_per_env * self.env.num_envs * self.world_size
         self.tot_timesteps += n_total
         self.tot_time += locs['collection_time'] + locs['learn_time']
         iteration_time = locs['collection_time'] + locs['learn_time']
-        stats = locs['ep_totals']           # [sum of returns, sum of lengths, count] of the episodes finished since the last log, all ranks
-        if stats[2] > 0:
-            self.rewbuffer.append(stats[0] / stats[2])
-            self.lenbuffer.append(stats[1] / stats[2])
         ep_string = ''
         if locs['ep_means']:
             # steps on which no env was reset anywhere carry NaN (no fresh episode entry in the reference): mean over the others
@@ -179,6 +185,12 @@ class OnPolicyRunner:
 
     def get_inference_policy(self, device=None):
         self.alg.actor_critic.eval()
-        if device is not None:
-            self.alg.actor_critic.to(device)
+        if device is not None and torch.device(device) != torch.device(self.device):
+            # the reference calls `.to(device)` here (play.py:58-59 passes env.device, the training device).  The parameters of this
+            # ActorCritic are VIEWS of the flat buffer the kernels read: moving the module would silently detach them.
+            same = torch.device(device).type == "cuda" and torch.device(self.device).type == "cuda" and \
+                (torch.device(device).index or 0) == (torch.device(self.device).index or 0)
+            if not same:
+                raise RuntimeError(f"get_inference_policy(device={device!r}): the policy lives in the kernels' flat parameter buffer on "
+                                   f"{self.device}; export it (helpers.export_policy_as_jit) or copy actor_critic.state_dict() to run it elsewhere")
         return self.alg.actor_critic.act_inference

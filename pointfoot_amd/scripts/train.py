@@ -7,6 +7,7 @@ import torch
 import torch.distributed as dist
 
 from pointfoot_amd.envs import *  # noqa: F401,F403  (registers the tasks)
+from pointfoot_amd import dp
 from pointfoot_amd.utils import get_args, task_registry
 
 
@@ -14,7 +15,7 @@ def _maybe_init_distributed(args):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")          # RCCL on ROCm
+        dp.init_process_group("nccl", local)     # RCCL on ROCm, bound to this rank's GPU (device_id)
         args.sim_device = args.rl_device = f"cuda:{local}"
 
 

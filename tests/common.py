@@ -40,13 +40,19 @@ def oracle_lib():
     return lib
 
 
-def emu_lib():
+def emu_build():
+    """compile (never load) the host build of the step program"""
     out = os.path.join(ROOT, "tests", "emu", "_build", "libpf_emu.so")
     srcs = [os.path.join(ROOT, "tests", "emu", "pf_emu.cpp")] + [
         os.path.join(ROOT, "pointfoot_amd", "csrc", f) for f in ("pf_step_kernel.h", "pf_simt.h", "pf_layout.h", "pf_lump.h")] + [
         os.path.join(ROOT, "include", "pointfoot_hip.h")]
     _build(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "tests/emu/pf_emu.cpp", "-o", out],
            out, srcs)
+    return out
+
+
+def emu_lib():
+    out = emu_build()
     lib = C.CDLL(out)
     lib.pfe_step.argtypes = [C.POINTER(_abi.PfModel), C.POINTER(_abi.PfConfig), C.POINTER(_abi.PfLayout),
                              C.POINTER(_abi.PfBuffers), C.c_void_p, C.c_longlong, C.POINTER(_abi.PfInject), C.c_int, C.c_void_p]
@@ -92,8 +98,10 @@ class HostSim:
         self.actuator = None if actuator is None else np.ascontiguousarray(actuator, np.float32)
         if self.actuator is None:
             self.c.use_actuator_net = 0
+        # the record layout comes from the HIP library's own pf_layout (a host-only entry point: no GPU needed), so a GPU test
+        # process never maps the CPU build of the kernel source; tests/test_host_logic.py cross-checks pfe_layout against it
         self.L = _abi.PfLayout()
-        assert emu_lib().pfe_layout(C.byref(self.model), C.byref(self.c), C.byref(self.L)) == 0
+        _abi.check(_abi.load().pf_layout(C.byref(self.model), C.byref(self.c), C.byref(self.L)))
         L = self.L
         self.state = np.zeros((n, L.rec_floats), np.float32)
         self.state[:, L.root + 6] = 1.0

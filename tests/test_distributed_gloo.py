@@ -1,6 +1,6 @@
 """world_size-2 tests of the N>1 path on CPU (gloo): (1) env sharding — two ranks of N envs produce exactly the
 observations of one process with 2N envs (Philox streams and terrain types are keyed by the GLOBAL env index);
-(2) data-parallel update — all-reducing per-shard gradients (+ KL tail) through pointfoot_amd.rsl_rl.dp and applying
+(2) data-parallel update — all-reducing per-shard gradients (+ KL tail) through pointfoot_amd.dp and applying
 clip + Adam gives the single-process result on the concatenated batch, with identical learning-rate decisions."""
 import os
 import sys
@@ -55,7 +55,7 @@ def _dp_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import ppo_ref
-    from pointfoot_amd.rsl_rl import dp
+    from pointfoot_amd import dp
     torch.manual_seed(100 + rank)                      # ranks start from DIFFERENT weights ...
     ac = ppo_ref.RefActorCritic(27, 27, 6, [32, 16], [32, 16])
     flat = ac.flat().clone()
@@ -110,7 +110,7 @@ class _FakeInfo(dict):
 def _ep_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from pointfoot_amd.rsl_rl import dp
+    from pointfoot_amd import dp
     # step 0: rank 0 reset 1 env (sums 2, 4), rank 1 reset 3 envs (sums 10, 20); step 1: nobody reset anything;
     # step 2: only rank 1 reset (2 envs)
     infos = [[_FakeInfo([2.0, 4.0], 1, 1.0), _FakeInfo([0.0, 0.0], 0, 1.0), _FakeInfo([0.0, 0.0], 0, 1.0)],
@@ -137,6 +137,62 @@ def test_episode_statistics_are_count_weighted_across_ranks(tmp_path):
     assert abs(red["terrain_level"] - 2.0) < 1e-6 and red["max_command_x"] == 1.5
     torch.testing.assert_close(r["tot"], torch.tensor([3.0, 20.0, 4.0]))
     # one rank alone: the plain per-step means
-    from pointfoot_amd.rsl_rl import dp
+    from pointfoot_amd import dp
     solo = dp.reduce_episode_infos([_FakeInfo([2.0, 4.0], 1, 1.0), _FakeInfo([0.0, 0.0], 0, 1.0)], "cpu")
     assert abs(solo["rew_a"] - 1.0) < 1e-6 and abs(solo["rew_b"] - 2.0) < 1e-6
+
+
+def _ring(entries, seen_steps):
+    """a PpoBuffers.d_ep_ring image holding `entries` = [(return, length, step, seq)], oldest first"""
+    import numpy as np
+    from pointfoot_amd import _abi
+    r = np.zeros(_abi.PPO_EP_RING_INTS, np.int32)
+    n = len(entries)
+    assert n <= _abi.PPO_EP_RING
+    head = 37                                    # somewhere in the ring: the merge must honour the wrap-around
+    for k, (ret, ln, stp, seq) in enumerate(entries):
+        slot = (head - n + k) % _abi.PPO_EP_RING
+        r[4 + 4 * slot: 8 + 4 * slot] = [np.float32(ret).view(np.int32), np.float32(ln).view(np.int32), stp, seq]
+    r[0], r[1], r[2], r[3] = head, n, (entries[-1][3] + 1 if entries else 0), seen_steps
+    return torch.from_numpy(r)
+
+
+def _ring_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pointfoot_amd import dp
+    import random
+    rng = random.Random(5)
+    # one process with 2 x 40 envs: per step a few envs finish; env e belongs to rank e // 40
+    seq = [0, 0]
+    mine, merged = [], []
+    for step in range(60):
+        for e in sorted(rng.sample(range(80), rng.choice([0, 1, 3, 9]))):
+            r = e // 40
+            item = (float(step * 100 + e), float(e + 1), step, seq[r])
+            seq[r] += 1
+            merged.append(item)
+            if r == rank:
+                mine.append(item)
+    rets, lens = dp.merge_episode_rings(_ring(mine[-100:], 60))
+    if rank == 0:
+        torch.save(dict(rets=rets, lens=lens, want_r=[m[0] for m in merged[-100:]], want_l=[m[1] for m in merged[-100:]]), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_episode_rings_of_two_ranks_merge_into_one_process_deque(tmp_path):
+    """Train/mean_reward and Train/mean_episode_length under data parallelism: the ranks' rings of finished episodes are
+    concatenated in the order ONE process with all the envs would have appended them -- (policy step, rank, position) -- and the
+    last 100 kept (rsl_rl: deque(maxlen=100))."""
+    out = str(tmp_path / "ring.pt")
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_ring_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=True)
+    assert len(r["rets"]) == 100 and r["rets"] == r["want_r"] and r["lens"] == r["want_l"]
+    # a single process: the ring itself, oldest first, across the wrap-around
+    from pointfoot_amd import dp
+    ents = [(1.5 * k, float(k), k // 3, k) for k in range(70)]
+    rets, lens = dp.merge_episode_rings(_ring(ents, 24))
+    assert rets == [e[0] for e in ents] and lens == [e[1] for e in ents]
+    assert dp.merge_episode_rings(_ring([], 0)) == ([], [])

@@ -237,7 +237,7 @@ def test_gemm_kernel_family_on_ragged_shapes(mode, path):
 def test_two_rank_shards_match_one_full_batch_handle():
     """The N>1 path through the HIP kernels, without a second GPU: two PpoAlg handles created with world_size = 2, each
     holding one env shard, against ONE handle holding all envs.  The collectives are done by hand exactly as
-    pointfoot_amd.rsl_rl.dp does them (sum of the 3 advantage scalars; sum of the flat gradient + KL tail), so this
+    pointfoot_amd.dp does them (sum of the 3 advantage scalars; sum of the flat gradient + KL tail), so this
     exercises gscale = 1 / world_size in ppo_minibatch_apply, the KL tail read by k_prepare_step and the global
     advantage normalisation.  Ranks must stay in lock-step bit for bit, and equal the full-batch run."""
     from pointfoot_amd.rsl_rl.modules import ActorCritic
@@ -362,7 +362,62 @@ def test_backward_in_two_parts_equals_the_whole_pass(hidden):
         torch.cuda.synchronize()
         assert torch.equal(early, whole[late.numel():]), "early range not final after part 0"
         assert bool((late == SENT).all()), "part 0 wrote into the late range"
+        # what the overlap relies on: part 1 never touches the EARLY range (its all-reduce is in flight by then -- a part 1 that
+        # rewrote it, even with the same local values, would overwrite the reduced sums on N > 1 ranks)
+        early.fill_(SENT)
         common._abi.check(lib.ppo_minibatch_backward_part(h, mb, 1, s), lib)
         torch.cuda.synchronize()
-        assert torch.equal(alg.grads, whole)
+        assert bool((early == SENT).all()), "part 1 wrote into the early range"
+        assert torch.equal(late, whole[:late.numel()])
     assert lib.ppo_minibatch_backward_part(h, 0, 2, s) != 0
+
+
+@pytest.mark.parametrize("env", [{"PF_PPO_PAIRED": "0"}, {"PF_PPO_FUSED_HEADS": "0"}])
+def test_update_under_collectives_without_the_paired_mode_keeps_the_blocking_path(env, monkeypatch):
+    """A handle that cannot cut the backward pass (ppo_supports_parts == 0) must say so: PPO.update then runs the whole pass and
+    one blocking all-reduce instead of failing inside ppo_minibatch_backward_part."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    N, T, O, P, A = 64, 4, 27, 148, 6
+    alg, ref = make(N, T, O, P, A, [64, 32], seed=2)
+    assert alg._lib.ppo_supports_parts(alg._h) == 0 and alg._grad_groups is None
+    assert alg._lib.ppo_minibatch_backward_part(alg._h, 0, 0, alg._stream()) != 0      # the library still refuses the cut
+    for k in env:
+        monkeypatch.delenv(k)
+    alg2, _ = make(N, T, O, P, A, [64, 32], seed=2)
+    assert alg2._lib.ppo_supports_parts(alg2._h) == 1 and alg2._grad_groups is not None
+
+
+def test_episode_ring_is_the_runners_deque_of_finished_episodes():
+    """rsl_rl v1.0.2 OnPolicyRunner.learn: cur_reward_sum += rewards; cur_episode_length += 1; for the envs done on this step,
+    in env order, rewbuffer / lenbuffer (deque(maxlen=100)) get the finished episode's return / length (call site
+    legged_gym/scripts/train.py:44).  The device-side ring (k_process + k_episode_ring, no host sync) must hold exactly that
+    deque after scripted episode ends -- sparse steps, a step with more than 100 ends at once, several rollouts."""
+    from collections import deque
+    from pointfoot_amd import dp
+    N, T, O, P, A = 300, 6, 27, 148, 6
+    alg, ref = make(N, T, O, P, A, [64, 32], seed=4)
+    gen = torch.Generator(device="cuda:0").manual_seed(9)
+    rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+    cur_r, cur_l = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    rates = [0.0, 0.002, 0.05, 0.6, 0.01, 0.0, 0.3, 0.003]
+    step = 0
+    for rollout in range(5):
+        for t in range(T):
+            obs, cobs = torch.randn(N, O, device="cuda:0", generator=gen), torch.randn(N, P, device="cuda:0", generator=gen)
+            alg.act(obs, cobs)
+            rew = torch.randn(N, device="cuda:0", generator=gen)
+            dones = torch.rand(N, device="cuda:0", generator=gen) < rates[step % len(rates)]
+            step += 1
+            alg.process_env_step(rew, dones, {"time_outs": dones & (torch.rand(N, device="cuda:0", generator=gen) < 0.5)})
+            cur_r += rew.cpu().numpy(); cur_l += 1
+            ids = np.nonzero(dones.cpu().numpy())[0]
+            rewbuffer.extend(cur_r[ids].tolist()); lenbuffer.extend(cur_l[ids].tolist())
+            cur_r[ids] = 0; cur_l[ids] = 0
+        alg.compute_returns(torch.randn(N, P, device="cuda:0", generator=gen))
+        alg.storage.clear()
+        rets, lens = dp.merge_episode_rings(alg.ep_ring)
+        assert lens == list(lenbuffer), f"rollout {rollout}: episode lengths differ from the deque"
+        np.testing.assert_allclose(rets, list(rewbuffer), rtol=1e-5, atol=1e-5)
+        assert int(alg.ep_ring[3]) == step and int(alg.ep_ring[1]) == len(rewbuffer)
+    assert len(rewbuffer) == 100

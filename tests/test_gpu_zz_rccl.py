@@ -28,7 +28,7 @@ def _update(seed=11):
 
 
 def test_update_through_a_single_rank_rccl_group_is_the_plain_update(monkeypatch):
-    from pointfoot_amd.rsl_rl import dp
+    from pointfoot_amd import dp
     base_params, base_lr, base_adv = _update()
     assert not dp.collectives_on()
     with socket.socket() as s:
@@ -36,7 +36,7 @@ def test_update_through_a_single_rank_rccl_group_is_the_plain_update(monkeypatch
         port = s.getsockname()[1]
     torch.cuda.set_device(0)
     try:
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     except Exception as ex:      # an image without a usable RCCL transport: nothing to rehearse
         pytest.skip(f"nccl process group of one rank did not come up: {ex!r}")
     try:

@@ -35,6 +35,11 @@ def test_pf_layout_host_only_and_error_reporting():
     L = _abi.PfLayout()
     assert lib.pf_layout(C.byref(sim.model), C.byref(sim.c), C.byref(L)) == 0
     assert bytes(L) == bytes(sim.L) and L.rec_floats % 16 == 0 and L.rand_floats >= 27 + 121 + 18
+    Le = _abi.PfLayout()      # the host build of the step program (tests/emu) lays the record out the same way
+    assert common.emu_lib().pfe_layout(C.byref(sim.model), C.byref(sim.c), C.byref(Le)) == 0 and bytes(Le) == bytes(L)
+    for task in ("flat", "anymal_c_rough", "anymal_c_flat"):
+        s2 = common.HostSim(common.make_cfg(task, 4), 4)
+        assert common.emu_lib().pfe_layout(C.byref(s2.model), C.byref(s2.c), C.byref(Le)) == 0 and bytes(Le) == bytes(s2.L), task
     assert lib.pf_layout(None, None, None) != 0 and b"null" in lib.pf_last_error()
     bad = _abi.PfModel.from_buffer_copy(bytes(sim.model)); bad.nb = 7
     assert not lib.pf_create(C.byref(bad), C.byref(sim.c), 0)
