@@ -62,7 +62,10 @@ def emu_lib():
     return lib
 
 
-def make_cfg(task, num_envs, control_type="P", add_noise=True):
+def make_cfg(task, num_envs, control_type="P", add_noise=True, variant=None):
+    """this repo's config instance for a test task name; `variant` / an "_allrew" / "_onlypos" suffix of a pointfoot task name
+    applies tests/golden/variants.py (the same function the golden generator applies to the reference's config)"""
+    import variants
     from pointfoot_amd.envs.pointfoot.mixed_terrain.pointfoot_rough_config import PointFootRoughCfg
     from pointfoot_amd.envs.pointfoot.flat.pointfoot_flat_config import PointFootFlatCfg
     if task.startswith("anymal"):
@@ -72,8 +75,9 @@ def make_cfg(task, num_envs, control_type="P", add_noise=True):
         cfg.env.num_envs = num_envs
         cfg.control.control_type = control_type
         cfg.noise.add_noise = add_noise
-        return cfg
+        return variants.apply(cfg, variant)
     cfg = PointFootRoughCfg() if task.startswith("rough") else PointFootFlatCfg()
+    variants.apply(cfg, variant if variant is not None else task)
     if task == "rough_hactor":      # point_foot.py:361: height measurements in the actor's observations too
         cfg.terrain.measure_heights_actor = True
         cfg.env.num_propriceptive_obs = 27 + len(cfg.terrain.measured_points_x) * len(cfg.terrain.measured_points_y)
@@ -193,7 +197,7 @@ def sim_from_golden(g, task, control_type="P", add_noise=True):
                  "last_max_feet_height"):
         sim.f(name, nf)[:] = g["init_" + name].astype(np.float32)
     sim.f("cur_max_feet_height", nf)[:] = g["init_current_max_feet_height"]
-    R = len(g["reward_names"])
+    R = g["init_episode_sums"].shape[0]          # reward terms (+ the termination sum, kept last, when its scale is non-zero)
     sim.f("episode_sums", R)[:] = g["init_episode_sums"].T
     sim.f("env_origin", 3)[:] = g["init_env_origins"]
     sim.episode_length[:] = g["init_episode_length"]

@@ -33,6 +33,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import synth  # noqa: E402
+import variants  # noqa: E402
 
 REF = os.environ.get("POINTFOOT_REFERENCE", "/root/reference")
 
@@ -191,6 +192,7 @@ def build_env(task, n, rng_seed, control_type="P"):
         cfg.terrain.measure_heights_actor = True
         cfg.env.num_propriceptive_obs = 27 + len(cfg.terrain.measured_points_x) * len(cfg.terrain.measured_points_y)
     rough = task.startswith("rough")
+    variants.apply(cfg, task)          # "..._allrew" / "..._onlypos" tasks (tests/golden/variants.py); a no-op for the others
     e = object.__new__(PointFoot)
     e.terminate = None
     e.cfg = cfg
@@ -295,6 +297,21 @@ def build_env(task, n, rng_seed, control_type="P"):
     return e, cfg
 
 
+def record_terms(e):
+    """wrap the env's bound reward functions so that what each returned inside step() is kept (harness only: calling them a
+    second time would advance LeggedRobot's feet-air-time state machine, legged_robot.py:882-893)"""
+    rec = {}
+
+    def wrap(i, fn):
+        def w():
+            v = fn()
+            rec[i] = v.detach().clone().to(torch.float32).numpy()
+            return v
+        return w
+    e.reward_functions = [wrap(i, f) for i, f in enumerate(e.reward_functions)]
+    return rec
+
+
 def scatter_rows(n, ids, t, width):
     out = np.zeros((n, width), dtype=np.float32)
     if len(ids):
@@ -305,6 +322,7 @@ def scatter_rows(n, ids, t, width):
 def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at=2):
     e, cfg = build_env(task, n, seed, control_type)
     rough = task.startswith("rough")
+    term_rec = record_terms(e) if "allrew" in task else None
     rl = RandLog(seed)
     torch.rand = rl.rand
     torch.rand_like = rl.rand_like
@@ -344,7 +362,13 @@ def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at
 
     out = {}
     names = list(e.reward_names)
+    # the termination term is not a reward *function* (point_foot.py:808-809) but has an episode sum (:818-820): kept last
+    sum_names = names + (["termination"] if "termination" in e.episode_sums else [])
     out["reward_names"] = np.array(names)
+    if len(sum_names) != len(names):
+        out["sum_names"] = np.array(sum_names)
+        out["termination_scale"] = np.array(e.reward_scales["termination"], np.float64)
+        out["only_positive_rewards"] = np.array(bool(cfg.rewards.only_positive_rewards))
     out["reward_scales"] = np.array([e.reward_scales[k] for k in names], dtype=np.float64)
     out["obs_noise_vec"] = e.noise_scale_vec[0].numpy()
     pv = e.noise_scale_vec[1]
@@ -380,7 +404,7 @@ def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at
         d["feet_height"] = e.feet_height.numpy().copy()
         d["current_max_feet_height"] = e.current_max_feet_height.numpy().copy()
         d["last_max_feet_height"] = e.last_max_feet_height.numpy().copy()
-        d["episode_sums"] = np.stack([e.episode_sums[k].numpy() for k in names]).copy()
+        d["episode_sums"] = np.stack([e.episode_sums[k].numpy() for k in sum_names]).copy()
         d["env_origins"] = e.env_origins.numpy().copy()
         if rough:
             d["terrain_levels"] = e.terrain_levels.numpy().copy()
@@ -392,6 +416,9 @@ def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at
         acts = rs.normal(0, 1.5, (n, 6)).astype(np.float32)
         acts[0, 0] = 250.0                       # exercises clip_actions (+-100)
         subs = [synth.synth_sim_state(rs, n, 9, 6, origins, feet, rough) for _ in range(4)]
+        if "allrew" in task:
+            for s_ in subs:      # joint speeds past the soft velocity limit (18 / 45 rad/s) on every third env: _reward_dof_vel_limits
+                s_["dof"][::3, :, 1] *= 6.0
         e.gym.dof_queue = [s["dof"] for s in subs]
         e.gym.post = subs[3]
         if t == 1:
@@ -466,9 +493,11 @@ def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at
         if rough:
             out[f"{p}_measured_heights"] = e.measured_heights.numpy().copy()
         out[f"{p}_ext_force"] = e.rigid_body_external_forces.numpy()[:, 0, :].copy()
+        if "allrew" in task:      # every term's value inside this step (the tests assert that every term is exercised)
+            out[f"{p}_terms"] = np.stack([term_rec[i] for i in range(len(names))])
         if len(ids):
             ep = extras["episode"]
-            out[f"{p}_extras_rew"] = np.array([float(ep["rew_" + k]) for k in e.episode_sums.keys()], np.float64)
+            out[f"{p}_extras_rew"] = np.array([float(ep["rew_" + k]) for k in sum_names], np.float64)
             if "terrain_level" in ep:
                 out[f"{p}_extras_terrain_level"] = np.array(float(ep["terrain_level"]))
         out.update(snap(p))
@@ -477,13 +506,14 @@ def run_sequence(task, n, steps, seed, control_type="P", add_noise=True, push_at
 
 
 # ----------------------------------------------------------------------------- LeggedRobot (anymal_c_rough) golden
-def build_env_lr(n, rng_seed, model):
+def build_env_lr(n, rng_seed, model, variant=None):
     """Construct the reference LeggedRobot (legged_gym/envs/base/legged_robot.py) with the anymal_c_rough config, bypassing
     the Isaac-Gym-bound constructors.  `model` = body/dof names of the collapsed ANYmal-C tree (pointfoot_amd URDF parser)."""
     from legged_gym.envs.base.legged_robot import LeggedRobot
     from legged_gym.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
     cfg = AnymalCRoughCfg()
     cfg.env.num_envs = n
+    variants.apply(cfg, variant)
     e = object.__new__(LeggedRobot)
     e.cfg = cfg
     e.sim_params = types.SimpleNamespace(dt=cfg.sim.dt, use_gpu_pipeline=False)
@@ -519,6 +549,8 @@ def build_env_lr(n, rng_seed, model):
     e.dof_pos_limits = torch.zeros(nd, 2); e.dof_vel_limits = torch.zeros(nd); e.torque_limits = torch.zeros(nd)
     for i in range(nd):      # _process_dof_props for env 0 (legged_robot.py:286-305)
         e.dof_pos_limits[i, 0] = model["q_lo"][i]; e.dof_pos_limits[i, 1] = model["q_hi"][i]
+        if variant and "allrew" in variant:      # ANYmal's joints carry no position limits: synthetic ones, so that
+            e.dof_pos_limits[i, 0], e.dof_pos_limits[i, 1] = -0.9 + 0.05 * i, 0.7 + 0.04 * i      # _reward_dof_pos_limits is exercised
         e.dof_vel_limits[i] = model["vel_limit"][i]; e.torque_limits[i] = model["effort_limit"][i]
         m = (e.dof_pos_limits[i, 0] + e.dof_pos_limits[i, 1]) / 2
         r = e.dof_pos_limits[i, 1] - e.dof_pos_limits[i, 0]
@@ -549,8 +581,10 @@ def build_env_lr(n, rng_seed, model):
     return e, cfg, feet
 
 
-def run_sequence_lr(n, steps, seed, model):
-    e, cfg, feet = build_env_lr(n, seed, model)
+def run_sequence_lr(n, steps, seed, model, variant=None):
+    e, cfg, feet = build_env_lr(n, seed, model, variant)
+    allrew = bool(variant) and "allrew" in variant
+    term_rec = record_terms(e) if allrew else None
     nb, nd = len(model["body_names"]), len(model["dof_names"])
     rl = RandLog(seed)
     torch.rand = rl.rand; torch.rand_like = rl.rand_like; torch.randint_like = rl.randint_like
@@ -567,6 +601,8 @@ def run_sequence_lr(n, steps, seed, model):
     e.commands[:, 0] = torch.from_numpy(rs.uniform(-1, 1, n)).float()
     e.commands[:, 1] = torch.from_numpy(rs.uniform(-1, 1, n)).float()
     e.commands[:, 3] = torch.from_numpy(rs.uniform(-3.14, 3.14, n)).float()
+    if allrew:
+        e.commands[::5, :2] = 0.0          # standing commands: _reward_stand_still (legged_robot.py:900-902)
     e.last_actions[:] = torch.from_numpy(rs.normal(0, 1, (n, nd))).float()
     e.last_dof_vel[:] = torch.from_numpy(rs.normal(0, 3, (n, nd))).float()
     e.feet_air_time[:] = torch.from_numpy(rs.uniform(0, 0.9, (n, 4))).float() * (torch.from_numpy(rs.uniform(size=(n, 4))) > 0.3)
@@ -574,25 +610,33 @@ def run_sequence_lr(n, steps, seed, model):
     for k in e.episode_sums:
         e.episode_sums[k][:] = torch.from_numpy(rs.normal(0, 1, n)).float()
     names = list(e.reward_names)
+    sum_names = names + (["termination"] if "termination" in e.episode_sums else [])
     out = dict(reward_names=np.array(names), reward_scales=np.array([e.reward_scales[k] for k in names], np.float64),
                noise_scale_vec=e.noise_scale_vec.numpy(), p_gains=e.p_gains.numpy(), d_gains=e.d_gains.numpy(),
                default_dof_pos=e.default_dof_pos.numpy().reshape(-1), terrain_types=e.terrain_types.numpy(),
                terrain_origins=e.terrain_origins.numpy(), feet_indices=np.array(feet),
                penalised_contact_indices=e.penalised_contact_indices.numpy(), termination_contact_indices=e.termination_contact_indices.numpy(),
                push_interval=np.array(cfg.domain_rand.push_interval), max_episode_length=np.array(e.max_episode_length))
+    if allrew:
+        out.update(sum_names=np.array(sum_names), termination_scale=np.array(e.reward_scales["termination"], np.float64),
+                   dof_pos_limits=e.dof_pos_limits.numpy().copy(), dof_vel_limits=e.dof_vel_limits.numpy().copy(),
+                   torque_limits=e.torque_limits.numpy().copy())
 
     def snap(prefix):
         d = dict(root=e.root_states.numpy().copy(), dof=e.dof_state.numpy().reshape(n, nd, 2).copy(),
                  episode_length=e.episode_length_buf.numpy().copy(), commands=e.commands.numpy().copy(),
                  last_actions=e.last_actions.numpy().copy(), last_dof_vel=e.last_dof_vel.numpy().copy(),
                  feet_air_time=e.feet_air_time.numpy().copy(), last_contacts=e.last_contacts.numpy().copy(),
-                 episode_sums=np.stack([e.episode_sums[k].numpy() for k in names]).copy(), env_origins=e.env_origins.numpy().copy(),
+                 episode_sums=np.stack([e.episode_sums[k].numpy() for k in sum_names]).copy(), env_origins=e.env_origins.numpy().copy(),
                  terrain_levels=e.terrain_levels.numpy().copy(), common_step_counter=np.array(e.common_step_counter))
         return {f"{prefix}_{k}": v for k, v in d.items()}
     out.update(snap("init"))
     for t in range(steps):
         acts = rs.normal(0, 1.0, (n, nd)).astype(np.float32)
         subs = [synth.synth_sim_state(rs, n, nb, nd, origins, feet, True) for _ in range(4)]
+        if allrew:
+            for s_ in subs:
+                s_["dof"][::3, :, 1] *= 6.0
         if t == 1:
             subs[3]["contact"][9:12, 0, :] = 7.0
         e.gym.dof_queue = [s["dof"] for s in subs]
@@ -646,10 +690,27 @@ def run_sequence_lr(n, steps, seed, model):
                     f"{p}_reset": reset.numpy().copy(), f"{p}_time_out": e.time_out_buf.numpy().copy(), f"{p}_torques": e.torques.numpy().copy(),
                     f"{p}_base_lin_vel": e.base_lin_vel.numpy().copy(), f"{p}_measured_heights": e.measured_heights.numpy().copy()})
         if len(ids):
-            out[f"{p}_extras_rew"] = np.array([float(extras["episode"]["rew_" + k]) for k in e.episode_sums.keys()], np.float64)
+            out[f"{p}_extras_rew"] = np.array([float(extras["episode"]["rew_" + k]) for k in sum_names], np.float64)
+        if allrew:
+            out[f"{p}_terms"] = np.stack([term_rec[i] for i in range(len(names))])
         out.update(snap(p))
     torch.rand = _orig_rand
     return out
+
+
+def feet_stumble_error():
+    """A non-zero `feet_stumble` scale: the reference looks up `_reward_feet_stumble`, which does not exist (the method is
+    `_reward_stumble`, point_foot.py:1226) -> AttributeError out of _prepare_reward_function (:814-815)."""
+    import types as _t
+    from legged_gym.envs.pointfoot.point_foot import PointFoot
+    e = object.__new__(PointFoot)
+    e.dt, e.num_envs, e.device = 0.02, 4, "cpu"
+    e.reward_scales = {"feet_stumble": -1.0, "torques": -1e-5}
+    try:
+        e._prepare_reward_function()
+    except AttributeError as ex:
+        return {"error_type": np.array("AttributeError"), "message": np.array(str(ex))}
+    return {"error_type": np.array("none"), "message": np.array("")}
 
 
 def anymal_model():
@@ -727,14 +788,27 @@ def main():
         return
     jobs = [("flat", 64, 6, 1, "P", True), ("rough", 64, 6, 2, "P", True),
             ("flat", 16, 2, 3, "V", False), ("flat", 16, 2, 4, "T", False), ("rough_hactor", 16, 3, 5, "P", True)]
+    # round 4: every reward term live (24 PointFoot methods / 19 LeggedRobot methods), and only_positive_rewards on PointFoot
+    allrew_jobs = [("rough_allrew", 64, 4, 7, "P", True), ("rough_allrew_onlypos", 32, 3, 8, "P", True), ("flat_allrew", 32, 3, 9, "P", False)]
     if len(sys.argv) > 1 and sys.argv[1] == "hactor":        # only the heights-in-actor-observations fixture
         jobs = jobs[-1:]
+    elif len(sys.argv) > 1 and sys.argv[1] == "allrew":      # only the round-4 fixtures
+        jobs = allrew_jobs
+    else:
+        jobs = jobs + allrew_jobs
     for task, n, steps, seed, ct, noise in jobs:
         out = run_sequence(task, n, steps, seed, ct, noise)
         fn = os.path.join(HERE, f"pf_{task}_{ct}_n{n}.npz")
         np.savez_compressed(fn, **out)
         print("wrote", fn, os.path.getsize(fn), "bytes; rewards:", list(out["reward_names"]))
     if len(sys.argv) > 1 and sys.argv[1] == "hactor":
+        return
+    out = run_sequence_lr(32, 4, 10, anymal_model(), variant="allrew")
+    fn = os.path.join(HERE, "lr_anymal_c_rough_allrew_n32.npz")
+    np.savez_compressed(fn, **out)
+    print("wrote", fn, os.path.getsize(fn), "bytes; rewards:", list(out["reward_names"]))
+    np.savez_compressed(os.path.join(HERE, "feet_stumble_error.npz"), **feet_stumble_error())
+    if len(sys.argv) > 1 and sys.argv[1] == "allrew":
         return
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc_vectors())
     out = run_sequence_lr(32, 5, 6, anymal_model())

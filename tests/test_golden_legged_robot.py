@@ -14,12 +14,17 @@ import common
 TOL = 1e-4
 
 
-def lr_sim_from_golden(g, actuator=None):
+def lr_sim_from_golden(g, actuator=None, variant=None):
     import synth
     n = g["init_root"].shape[0]
-    cfg = common.make_cfg("anymal_c_rough", n)
+    cfg = common.make_cfg("anymal_c_rough", n, variant=variant)
     sim = common.HostSim(cfg, n, hf=synth.synth_heightfield(), terrain_origins=g["terrain_origins"], actuator=actuator)
     nd = 12
+    if "dof_pos_limits" in g:      # the all-rewards fixture gives the (limit-free) ANYmal joints synthetic soft limits
+        for i in range(nd):
+            sim.c.dof_pos_soft_lo[i], sim.c.dof_pos_soft_hi[i] = g["dof_pos_limits"][i]
+        np.testing.assert_allclose([sim.c.dof_vel_limits[i] for i in range(nd)], g["dof_vel_limits"], rtol=1e-6)
+        np.testing.assert_allclose([sim.c.torque_limits[i] for i in range(nd)], g["torque_limits"], rtol=1e-6)
     sim.f("root", 13)[:] = g["init_root"]
     sim.f("dof_pos", nd)[:] = g["init_dof"][:, :, 0]
     sim.f("dof_vel", nd)[:] = g["init_dof"][:, :, 1]
@@ -28,7 +33,7 @@ def lr_sim_from_golden(g, actuator=None):
     sim.f("last_dof_vel", nd)[:] = g["init_last_dof_vel"]
     sim.f("feet_air_time", 4)[:] = g["init_feet_air_time"]
     sim.f("last_contacts", 4)[:] = g["init_last_contacts"].astype(np.float32)
-    sim.f("episode_sums", len(g["reward_names"]))[:] = g["init_episode_sums"].T
+    sim.f("episode_sums", g["init_episode_sums"].shape[0])[:] = g["init_episode_sums"].T
     sim.f("env_origin", 3)[:] = g["init_env_origins"]
     sim.episode_length[:] = g["init_episode_length"]
     sim.terrain_level[:] = g["init_terrain_levels"]
@@ -81,11 +86,12 @@ def lr_check_step(sim, g, t, names):
     close("last_dof_vel", sim.f("last_dof_vel", 12), g[p + "_last_dof_vel"])
     close("feet_air_time", sim.f("feet_air_time", 4), g[p + "_feet_air_time"], 1e-5)
     assert np.array_equal(sim.f("last_contacts", 4) != 0, g[p + "_last_contacts"])
-    close("episode_sums", sim.f("episode_sums", len(names)).T, g[p + "_episode_sums"])
+    nsum = g[p + "_episode_sums"].shape[0]          # len(names) (+ 1: the termination sum, kept last)
+    close("episode_sums", sim.f("episode_sums", nsum).T, g[p + "_episode_sums"])
     close("env_origins", sim.f("env_origin", 3), g[p + "_env_origins"])
     nreset = int(g[p + "_reset"].sum())
     if nreset:
-        close("extras_rew", sim.stats[:len(names)] / nreset / sim.c.max_episode_length_s, g[p + "_extras_rew"], 1e-4)
+        close("extras_rew", sim.stats[:nsum] / nreset / sim.c.max_episode_length_s, g[p + "_extras_rew"], 1e-4)
 
 
 @pytest.mark.parametrize("backend", ["oracle", "emu"])
@@ -112,6 +118,27 @@ def test_legged_robot_python_layer_matches_reference(backend):
         saw["push"] |= bool(g[f"s{t}_pushed"]); saw["reset"] |= bool(g[f"s{t}_reset"].any())
         saw["resample"] |= bool(np.abs(g[f"s{t}_r_cmd"]).sum() > 0)
     assert all(saw.values()), saw      # the fixture exercises the velocity push, the periodic resample and resets
+
+
+@pytest.mark.parametrize("backend", ["oracle", "emu"])
+def test_legged_robot_all_reward_terms_match_reference(backend):
+    """All 19 `_reward_*` methods of legged_robot.py:816-906 with a non-zero scale (tests/golden/variants.py), under
+    only_positive_rewards (anymal_c_rough_config.py:86): the sum clipped at 0, then the termination term (legged_robot.py:201-207)."""
+    g = common.load_golden("lr_anymal_c_rough_allrew_n32")
+    sim = lr_sim_from_golden(g, variant="allrew")
+    names = list(g["reward_names"])
+    assert sim.reward_names == names and len(names) == 18 and sim.c.only_positive_rewards == 1
+    assert abs(sim.c.termination_scale - float(g["termination_scale"])) < 1e-7
+    np.testing.assert_allclose([sim.c.reward_scale[i] for i in range(len(names))], g["reward_scales"], rtol=1e-6)
+    hits = sum((g[f"s{t}_terms"] != 0).sum(1) for t in range(4))
+    assert (hits >= 4).all(), dict(zip(names, hits))
+    counter = int(g["init_common_step_counter"])
+    keep = []
+    for t in range(4):
+        counter += 1
+        inj, _ = lr_inject(g, t, sim, keep)
+        sim.step(backend, g[f"s{t}_actions"], counter, C.byref(inj))
+        lr_check_step(sim, g, t, names)
 
 
 def _act_table():

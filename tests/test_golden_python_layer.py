@@ -11,7 +11,11 @@ import common
 TOL = 1e-4
 CASES = [("pf_flat_P_n64", "flat", "P", True, 6), ("pf_rough_P_n64", "rough", "P", True, 6),
          ("pf_flat_V_n16", "flat", "V", False, 2), ("pf_flat_T_n16", "flat", "T", False, 2),
-         ("pf_rough_hactor_P_n16", "rough_hactor", "P", True, 3)]      # cfg.terrain.measure_heights_actor (point_foot.py:361)
+         ("pf_rough_hactor_P_n16", "rough_hactor", "P", True, 3),      # cfg.terrain.measure_heights_actor (point_foot.py:361)
+         # round 4: all 24 `_reward_*` methods of point_foot.py:1132-1253 live (tests/golden/variants.py), and the
+         # only_positive_rewards branch (:312) with the termination term added after the clip (:314-317)
+         ("pf_rough_allrew_P_n64", "rough_allrew", "P", True, 4), ("pf_rough_allrew_onlypos_P_n32", "rough_allrew_onlypos", "P", True, 3),
+         ("pf_flat_allrew_P_n32", "flat_allrew", "P", False, 3)]
 
 
 def check_step(sim, g, t, rough, names):
@@ -52,7 +56,8 @@ def check_step(sim, g, t, rough, names):
         close(nm, sim.f(nm, 2), g[f"{p}_{gn}"], 1e-5)
     for nm in ("contact_filt", "first_contact", "last_contacts"):
         assert np.array_equal(sim.f(nm, 2) != 0, g[f"{p}_{nm}"]), f"step {t} {nm}"
-    close("episode_sums", sim.f("episode_sums", len(names)).T, g[p + "_episode_sums"])
+    nsum = g[p + "_episode_sums"].shape[0]          # len(names) (+ 1: the termination sum, kept last)
+    close("episode_sums", sim.f("episode_sums", nsum).T, g[p + "_episode_sums"])
     close("env_origins", sim.f("env_origin", 3), g[p + "_env_origins"])
     if bool(g[p + "_pushed"]):
         close("ext_force", sim.f("ext_force", 3), g[p + "_ext_force"], 1e-4)
@@ -60,7 +65,7 @@ def check_step(sim, g, t, rough, names):
     nreset = int(g[p + "_reset"].sum())
     if nreset:
         # extras["episode"]["rew_*"] = mean(episode_sums[ids]) / max_episode_length_s   (point_foot.py:276-280)
-        got = sim.stats[:len(names)] / nreset / sim.c.max_episode_length_s
+        got = sim.stats[:nsum] / nreset / sim.c.max_episode_length_s
         close("extras_rew", got, g[p + "_extras_rew"], 1e-4)
         assert sim.stats[common._abi.PF_MAX_REWARDS] == nreset
     return err
@@ -73,6 +78,15 @@ def test_python_layer_matches_reference(backend, fname, task, ctrl, noise, steps
     sim = common.sim_from_golden(g, task, ctrl, noise)
     names = list(g["reward_names"])
     assert sim.reward_names == names                      # G1: alphabetical summation order
+    if "allrew" in task:
+        # every reward method the reference class defines is live and non-trivially exercised by the fixture
+        assert len(names) == 23 and "termination_scale" in g and abs(sim.c.termination_scale - float(g["termination_scale"])) < 1e-7
+        assert sim.c.only_positive_rewards == int(bool(g["only_positive_rewards"])) == int("onlypos" in task)
+        hits = sum((g[f"s{t}_terms"] != 0).sum(1) for t in range(steps))
+        assert (hits >= 4).all(), dict(zip(names, hits))
+        if "onlypos" in task:      # the clip bites: some env's sum is negative and comes out as 0 (+ the termination term)
+            raw = sum((g["s0_terms"][i] * g["reward_scales"][i]) for i in range(len(names)))
+            assert (raw < -0.1).sum() >= 4 and g["s0_rew"].min() >= float(g["termination_scale"]) - 1e-6
     np.testing.assert_allclose([sim.c.reward_scale[i] for i in range(len(names))], g["reward_scales"], rtol=1e-6)
     np.testing.assert_allclose([sim.c.obs_noise_vec[i] for i in range(len(g["obs_noise_vec"]))], g["obs_noise_vec"], rtol=1e-6)   # G2
     if task.startswith("rough") and len(g["priv_noise_vec"]):
@@ -101,3 +115,16 @@ def test_misc_math_vectors():
     np.testing.assert_allclose(wrap_to_pi(torch.from_numpy(g["wrap_in"].copy())).numpy(), g["wrap_out"], atol=1e-6)
     out = quat_apply_yaw(torch.from_numpy(g["qay_q"]), torch.from_numpy(g["qay_v"])).numpy()
     np.testing.assert_allclose(out, g["qay_out"], atol=1e-6)
+
+
+def test_nonzero_feet_stumble_scale_raises_like_the_reference():
+    """`feet_stumble` in the configs has no `_reward_feet_stumble` method behind it (the method is `_reward_stumble`,
+    point_foot.py:1226): with a non-zero scale the reference raises AttributeError out of _prepare_reward_function (:814-815).
+    The fixture holds the reference's exception type and message."""
+    g = common.load_golden("feet_stumble_error")
+    assert str(g["error_type"]) == "AttributeError"
+    cfg = common.make_cfg("rough", 4)
+    cfg.rewards.scales.feet_stumble = -1.0
+    with pytest.raises(AttributeError) as ei:
+        common.HostSim(cfg, 4, hf=np.zeros((1300, 2100), np.int16), terrain_origins=np.zeros((10, 20, 3), np.float32))
+    assert str(ei.value) == str(g["message"])

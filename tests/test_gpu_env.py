@@ -440,6 +440,23 @@ def test_hip_legged_robot_python_layer_matches_reference_golden():
     hip.close()
 
 
+def test_hip_legged_robot_all_reward_terms_match_reference_golden():
+    """the 19 reward methods of legged_robot.py:816-906 all live, on the quadruped kernel instance"""
+    from test_golden_legged_robot import lr_sim_from_golden, lr_inject, lr_check_step
+    g = common.load_golden("lr_anymal_c_rough_allrew_n32")
+    sim = lr_sim_from_golden(g, variant="allrew")
+    hip = common.HipMirror(sim)
+    names = list(g["reward_names"])
+    counter = int(g["init_common_step_counter"])
+    keep = []
+    for t in range(4):
+        counter += 1
+        _, arrs = lr_inject(g, t, sim, keep)
+        hip.step(g[f"s{t}_actions"], counter, arrs)
+        lr_check_step(sim, g, t, names)
+    hip.close()
+
+
 def test_hip_anymal_full_step_matches_oracle():
     """17-body/12-DOF instance, actuator-network torques, LeggedRobot python layer, Philox noise: HIP vs oracle."""
     from test_golden_legged_robot import act_params
