@@ -280,6 +280,76 @@ def test_hip_flat_4096_literal_config():
     hip.close()
 
 
+def test_hip_rough_4096_literal_config():
+    """BASELINE config 3 as written, at full size, through the env class: `task_registry.make_env("pointfoot_rough")` with 4096
+    envs on its real curriculum terrain (trimesh collision surface, 121-point height scan in the critic observations), friction /
+    mass / COM randomisation, observation noise and pushes ON (pointfoot_rough_config.py:3-213).  After a few steps of settling the
+    env's state is mirrored into the oracle before every step, 10 steps with a PUSH step inside the window; strict 1e-4 on obs /
+    privileged obs / reward for every env whose discrete decisions agree (the rule of _full_step_parity), fractions recorded."""
+    import torch
+    from pointfoot_amd.envs import task_registry
+    from pointfoot_amd.utils import get_args
+    n, steps = 4096, 10
+    args = get_args(["--task", "pointfoot_rough", "--headless", "--num_envs", str(n), "--sim_device", "cuda:0", "--rl_device", "cuda:0"])
+    env, cfg = task_registry.make_env("pointfoot_rough", args=args)
+    c = env._cfg_c
+    assert c.add_noise == 1 and c.push_robots == 1 and c.terrain_type == common._abi.PF_TERRAIN_HEIGHTFIELD and c.num_height_points == 121
+    assert c.hf_rows == 1300 and c.hf_cols == 2100 and c.curriculum == 1 and env.num_privileged_obs == 148
+    assert cfg.domain_rand.randomize_friction and cfg.domain_rand.randomize_base_mass and cfg.domain_rand.randomize_base_com
+    assert float(env._state[:, env._L.friction].std()) > 0.1 and float(env._state[:, env._L.added_mass].std()) > 0.1
+    env.reset()
+    env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=1000)      # the runner's random episode start
+    rs = np.random.RandomState(11)
+    for _ in range(12):      # settle: robots land on their tiles, some fall and are reset by the kernel
+        env.step(torch.from_numpy(rs.normal(0, 0.5, (n, 6)).astype(np.float32)))
+    env.common_step_counter = int(c.push_interval) - 4      # the push (every 350 steps, point_foot.py:590-611) falls inside the window
+    sim = common.HostSim(cfg, n, hf=env.height_samples.cpu().numpy(), terrain_origins=env.terrain_origins.cpu().numpy())
+    sim.c = c
+    assert bytes(sim.L) == bytes(env._L)
+    sim.bufs = sim.make_bufs()
+    ref64, got = sim.clone(), sim.clone()
+    cset = env.bind_contact_set()
+    common.oracle_lib().pfo_set_threads(8)
+    stats = {"n": 0, "loose": 0}
+    flipped, scan_flips, pushed_steps, resets, faces = 0, 0, 0, 0, 0
+    try:
+        for t in range(steps):
+            torch.cuda.synchronize()
+            for s_ in (sim, ref64):
+                s_.state[:] = env._state.cpu().numpy()
+                s_.episode_length[:] = env.episode_length_buf.cpu().numpy()
+                s_.terrain_level[:] = env.terrain_levels.cpu().numpy(); s_.terrain_type[:] = env.terrain_types.cpu().numpy()
+            act = rs.normal(0, 0.7, (n, 6)).astype(np.float32)
+            o, p, r, d, _ = env.step(torch.from_numpy(act))
+            k = env.common_step_counter
+            pushed_steps += int(k % int(c.push_interval) == 0)
+            sim.step("oracle", act, k)
+            ref64.step("oracle", act, k, physics_bits=64)
+            torch.cuda.synchronize()
+            got.state[:] = env._state.cpu().numpy(); got.reset[:] = d.cpu().numpy()
+            got.contact_set[:] = cset.cpu().numpy().view(np.uint64)
+            got.obs[:], got.priv[:], got.rew[:] = o.cpu().numpy(), p.cpu().numpy(), r.cpu().numpy()
+            m = _same_decisions(got, sim)
+            flipped += int((~m).sum()); resets += int(sim.reset.sum())
+            faces += int((((sim.contact_set[:, :, 0] >> np.uint64(sim.model.nsph)) & np.uint64((1 << sim.model.nsph) - 1)) != 0).any(axis=1).sum())
+            _conditioned_close(f"step {t} obs", got.obs, sim.obs, ref64.obs, m, stats)
+            _conditioned_close(f"step {t} rew", got.rew, sim.rew, ref64.rew, m, stats, rtol=1e-4)
+            _conditioned_close(f"step {t} priv", got.priv[:, :27], sim.priv[:, :27], ref64.priv[:, :27], m, stats)
+            kf, _ = _height_scan_flips(got, sim, m & (np.abs(ref64.obs - sim.obs).max(axis=1) <= 1e-4 / KAPPA), 27)
+            scan_flips += kf
+            assert (env.episode_length_buf.cpu().numpy()[m] == sim.episode_length[m]).all()
+            assert (env.terrain_levels.cpu().numpy()[m] == sim.terrain_level[m]).all()
+    finally:
+        common.oracle_lib().pfo_set_threads(1)
+    total = steps * n
+    common.record_parity("test_hip_rough_4096_literal_config", env_steps=total, flipped=flipped, flipped_frac=flipped / total,
+                         scan_point_flips=scan_flips, allowance_checks=stats["loose"], checks=stats["n"], push_steps=pushed_steps,
+                         resets=resets, env_steps_with_face_contact=faces)
+    assert pushed_steps == 1 and resets > 0
+    assert flipped <= 0.003 * total, f"{flipped} of {total} env-steps took a different discrete branch"
+    assert stats["loose"] <= 0.001 * stats["n"] and scan_flips <= 40
+
+
 def test_hip_quadruped_self_contacts_match_oracle():
     """The quadruped instance built WITH self-collision (12 capsules / 54 pairs, 98 contact candidates: asset.self_collisions = 0,
     anymal_c_flat_config.py:42) on the GPU, in the crossed-legs scenario of tests/test_physics_invariants.py: same contact sets as the
