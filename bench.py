@@ -199,6 +199,100 @@ def cpu_baseline(task, num_envs, threads):
                 host_cpus=os.cpu_count(), cpu_model=cpu_model())
 
 
+class PowerSampler:
+    """Socket power and shader clock WHILE the timed loop runs (its real duty cycle: ~10 ms of GEMM-bound update, ~4 ms of
+    latency-bound rollout per iteration), from a side thread: the amdgpu hwmon / pp_dpm_sclk files of the card when readable (no
+    process start, ~20 samples a second), else `rocm-smi --json` (a few samples a second).  Host-side only; nothing touches the
+    GPU queue."""
+
+    def __init__(self, period=0.05, pci_bus_id=None):
+        import glob
+        import threading
+        self.period, self.samples, self._stop = period, [], False
+        self.src = None
+        devs = sorted(glob.glob("/sys/class/drm/card*/device"))
+        if pci_bus_id is not None:
+            # a GPU box shows this process ONE of the host's cards: take the hwmon files of the card on the same PCI bus
+            mine = [d for d in devs if os.path.basename(os.path.realpath(d)).lower().split(":")[1:2] == [f"{pci_bus_id:02x}"]]
+            devs = mine if mine else []
+        for dev in devs:
+            hw = glob.glob(os.path.join(dev, "hwmon", "hwmon*"))
+            if hw and os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+                pw = [f for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw[0], f))]
+                if pw:
+                    self.src = ("sysfs", os.path.join(hw[0], pw[0]), os.path.join(dev, "pp_dpm_sclk"),
+                                os.path.join(hw[0], "freq1_input") if os.path.exists(os.path.join(hw[0], "freq1_input")) else None,
+                                os.path.join(hw[0], "power1_cap") if os.path.exists(os.path.join(hw[0], "power1_cap")) else None)
+                    break
+        if self.src is None:
+            import shutil
+            if shutil.which("rocm-smi"):
+                self.src = ("rocm-smi",)
+                self.period = max(period, 0.15)
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        if self.src[0] == "sysfs":
+            _, pw, dpm, freq, _cap = self.src
+            with open(pw) as f:
+                watts = int(f.read().strip()) / 1e6
+            mhz = None
+            if freq:
+                with open(freq) as f:
+                    mhz = int(f.read().strip()) / 1e6
+            else:
+                with open(dpm) as f:
+                    for ln in f:
+                        if "*" in ln:
+                            mhz = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            return watts, mhz
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+        card = next(iter(json.loads(out).values()))
+        watts = next((float(v) for k, v in card.items() if "Power" in k and "W" in k), None)
+        sclk = next((v for k, v in card.items() if k.startswith("sclk")), None)
+        mhz = float(str(sclk).lower().replace("mhz", "").strip("() ")) if sclk is not None else None
+        return watts, mhz
+
+    def _run(self):
+        while not self._stop:
+            try:
+                w, m = self._read()
+                self.samples.append((time.perf_counter(), w, m))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def one(self):
+        try:
+            w, m = self._read()
+            return {"socket_w": w, "sclk_mhz": m}
+        except Exception:
+            return None
+
+    def start(self):
+        if self.src is not None:
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread.is_alive():
+            self._thread.join(timeout=2)
+
+    def summary(self, t0, t1):
+        inside = [(w, m) for t, w, m in self.samples if t0 <= t <= t1]
+        st = lambda v: ({"min": float(min(v)), "median": float(np.median(v)), "max": float(max(v))} if v else None)
+        cap = None
+        if self.src and self.src[0] == "sysfs" and self.src[4]:
+            try:
+                with open(self.src[4]) as f:
+                    cap = int(f.read().strip()) / 1e6
+            except Exception:
+                pass
+        return {"source": (self.src[0] + (":" + self.src[1].split("/device/")[0].rsplit("/", 1)[-1] if self.src[0] == "sysfs" else "")) if self.src else None,
+                "samples": len(inside), "power_cap_w": cap,
+                "socket_w": st([w for w, _ in inside if w is not None]), "sclk_mhz": st([m for _, m in inside if m is not None])}
+
+
 def usable_cpus():
     """cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (a GPU box hands each job a
     share of a much larger host; os.cpu_count() reports the whole host)"""
@@ -303,9 +397,13 @@ def main():
             up_pairs.append((s, e))
         return obs, cobs
 
+    sampler = PowerSampler(pci_bus_id=getattr(torch.cuda.get_device_properties(local), "pci_bus_id", None)) if rank == 0 else None
+    power_idle = sampler.one() if sampler and sampler.src else None
     for _ in range(a.warmup):
         obs, cobs = iteration(obs, cobs, False)
     torch.cuda.synchronize()
+    if sampler:
+        sampler.start()
     if rank == 0:
         print(f"[bench] warm-up done ({a.warmup} iterations)", file=sys.stderr, flush=True)
     if dist_on:
@@ -320,7 +418,26 @@ def main():
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    dt = t_end - t0
+    power = None
+    if sampler:
+        sampler.stop()
+        power = sampler.summary(t0, t_end)
+        power["before_warmup"] = power_idle
+        if power["samples"] < 4 and sampler.src:
+            # a timed region shorter than a few sampling periods: run the same alternating loop (untimed) until there are samples
+            sampler2 = PowerSampler(pci_bus_id=getattr(torch.cuda.get_device_properties(local), "pci_bus_id", None)); sampler2.start()
+            t2 = time.perf_counter()
+            while time.perf_counter() - t2 < 1.5:
+                obs, cobs = iteration(obs, cobs, False)
+                torch.cuda.synchronize()
+            sampler2.stop()
+            power = sampler2.summary(t2, time.perf_counter())
+            power["before_warmup"] = power_idle
+            power["note"] = "sampled over 1.5 s of the same alternating rollout / update loop run again after the timed region (the timed region was shorter than the sampling needs)"
+        else:
+            power["note"] = "sampled inside the timed region (rollout and update alternating as timed)"
     if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -437,6 +554,7 @@ def main():
             "phase_ms": {"env_step_launch": step_ms, "ppo_update": upd_ms, "iteration": dt / a.steps * 1e3,
                          "rollout": float(np.mean(col_ms)), "median": {"iteration": med(it_ms), "rollout": med(col_ms), "ppo_update": med(upd_all),
                                                                        "env_step_launch": med([s.elapsed_time(e) for s, e in ev_pairs])}},
+            "power": power,
             "median_value": n_gpus * per_iter_steps / (med(it_ms) * 1e-3),
             "collection_rate": {"value": n_gpus * per_iter_steps / (med(col_ms) * 1e-3), "unit": "env-steps/s",
                                 "note": "collection only: 24 x [policy forward + fused env step + transition store] + GAE, median iteration, this rank's device time"},

@@ -33,9 +33,12 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // WPB wavefronts per workgroup (each with RPW robots) share one read-only block (model, actuator parameters) in LDS; the
 // rest of the LDS is per robot.  WAVES = waves per SIMD the register budget is sized for.  LDS comes as dynamic shared
 // memory (the quadruped workgroup of 8 robots needs ~145 KB, above the static limit).
-template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0), int NBD = NB>
-__global__ __launch_bounds__(64 * WPB, WPB == 1 ? WAVES : 1) void pf_step_kernel(const void* __restrict__ packed, const PfConfig* __restrict__ cfg, PfStepArgs g) {
-  using K = PfKernel<NB, ND, NF, KIND, KS, RPW, KPR, NBD>;
+// DUAL: a workgroup is TWO wavefronts for the same RPW robots (WPB == 1): wave 0 runs the step, wave 1 the contact side of its
+// substeps (PfKernel::run, role).
+template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0), int NBD = NB, bool DUAL = false>
+__global__ __launch_bounds__(64 * WPB * (DUAL ? 2 : 1), (WPB == 1 || DUAL) ? WAVES : 1) void pf_step_kernel(const void* __restrict__ packed, const PfConfig* __restrict__ cfg, PfStepArgs g) {
+  using K = PfKernel<NB, ND, NF, KIND, KS, RPW, KPR, NBD, DUAL>;
+  static_assert(!DUAL || WPB == 1, "a DUAL workgroup is one pair of wavefronts");
   extern __shared__ __attribute__((aligned(16))) unsigned char pf_lds[];
   typename K::SharedRO& ro = *reinterpret_cast<typename K::SharedRO*>(pf_lds);
   typename K::Shared* sh = reinterpret_cast<typename K::Shared*>(pf_lds + ((sizeof(typename K::SharedRO) + 15) & ~size_t(15)));
@@ -43,10 +46,11 @@ __global__ __launch_bounds__(64 * WPB, WPB == 1 ? WAVES : 1) void pf_step_kernel
   // the slot the *next* launch accumulates into is cleared here, so a rollout needs no memset between steps
   if (blockIdx.x == 0 && g.stats_next && threadIdx.x < PF_STATS_FLOATS) g.stats_next[threadIdx.x] = 0.0f;
   // each group of 64 / RPW lanes runs the phase program on its own robot and its own LDS block
-  const int slot = (int)threadIdx.x / (64 / RPW);            // robot slot inside the workgroup
+  const int tid = DUAL ? ((int)threadIdx.x & 63) : (int)threadIdx.x;
+  const int slot = tid / (64 / RPW);                         // robot slot inside the workgroup
   const int env = (int)blockIdx.x * (RPW * WPB) + slot;
   if (env >= cfg->num_envs) return;
-  K::run(sh[slot], ro, g, env);
+  K::run(sh[slot], ro, g, env, DUAL ? ((int)threadIdx.x >> 6) : 0);
 }
 template <class K, int RPW, int WPB>
 static constexpr size_t pf_lds_bytes() {
@@ -111,7 +115,13 @@ static int pf_instance(const PfModel* m, const PfConfig* c) {
 }
 // dynamics on the models with their feet lumped into the shanks: 9 -> 7 bodies (PointFoot), 17 -> 13 (quadrupeds)
 constexpr int PF_NBD_POINTFOOT = 7, PF_NBD_QUAD = 13;
-using PfKernelPoint = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 16, PF_NBD_POINTFOOT>;
+// PointFoot instance: two wavefronts per pair of robots (PfKernel DUAL: the contact side of every substep, the observation noise
+// and the height scan run on a partner wavefront beside the dynamics).  94.8 -> 89.2 us per 4096-env launch on the same box;
+// -DPF_POINT_DUAL=0 builds the single-wavefront form (tools/build_variant.sh for A/B runs).
+#ifndef PF_POINT_DUAL
+#define PF_POINT_DUAL 1
+#endif
+using PfKernelPoint = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 16, PF_NBD_POINTFOOT, PF_POINT_DUAL != 0>;
 using PfKernelQuad = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 0, PF_NBD_QUAD>;
 using PfKernelQuadSelf = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_KPAIR_QUAD, PF_NBD_QUAD>;
 static int pf_validate(const PfModel* m, const PfConfig* c) {
@@ -269,7 +279,8 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   };
   if (e->instance == 2) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, PF_KPAIR_QUAD, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuadSelf, 1, 8>(), 8, 512);
   else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, 0, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuad, 1, 8>(), 8, 512);
-  else launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 1, 16, PF_NBD_POINTFOOT>, pf_lds_bytes<PfKernelPoint, 2, 1>(), 2, 64);
+  else if (PF_POINT_DUAL) launch(pf_step_kernel<9, 6, 2, 4, PF_KIND_POINTFOOT, PF_KSPH, 2, 1, 16, PF_NBD_POINTFOOT, PF_POINT_DUAL != 0>, pf_lds_bytes<PfKernelPoint, 2, 1>(), 2, 128);
+  else launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 1, 16, PF_NBD_POINTFOOT, false>, pf_lds_bytes<PfKernelPoint, 2, 1>(), 2, 64);
   PF_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -18,6 +18,9 @@
 #define PF_DEV static inline
 #define PF_LANES(i, n) for (int i = 0; i < (n); ++i)
 #define PF_SYNC() ((void)0)
+#define PF_XSYNC() ((void)0)
+#define PF_HANDOFF_SET(flag, token) ((void)0)
+#define PF_HANDOFF_WAIT(flag, token) ((void)0)
 #define PF_ONE if (true)
 #define PF_WAVE_SUM(x) (x)
 #define PF_WAVE_MAX(x) (x)
@@ -52,6 +55,28 @@ PF_DEV void pf_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 #define PF_SYNC() pf_wave_sync()
+// DUAL kernel instances (pf_step_kernel.h): the two wavefronts that share a group of robots meet at a workgroup barrier; LDS
+// written before it by one is visible to the other after it
+PF_DEV void pf_group_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#define PF_XSYNC() pf_group_sync()
+// One-way hand-off between the two wavefronts of a DUAL group without a barrier: the producer's LDS writes, then (LDS operations
+// of a wavefront execute in order) a token in a flag word; the consumer polls the flag before it reads.  The step clears the flag before its first
+// substep and every substep has a token of its own, so a stale flag never matches.
+PF_DEV void pf_handoff_set(int* flag, int token, bool one) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (one) __hip_atomic_store(flag, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+PF_DEV void pf_handoff_wait(int* flag, int token) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != token) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#define PF_HANDOFF_SET(flag, token) pf_handoff_set(&(flag), (token), PF_LANE_ID == 0)
+#define PF_HANDOFF_WAIT(flag, token) pf_handoff_wait(&(flag), (token))
 #define PF_ONE if (PF_LANE_ID == 0)
 template <int W>
 PF_DEV float pf_wave_sum(float v) {

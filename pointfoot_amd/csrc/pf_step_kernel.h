@@ -18,7 +18,17 @@
 #define PF_MAX_CHAINS 8
 #define PF_MAX_CHAIN_DEPTH 8
 #include <cmath>
+#include <type_traits>
 #include "pf_lump.h"
+#ifndef PF_DUAL_INERTIA
+#define PF_DUAL_INERTIA 0  /* DUAL instances: 1 = the partner wavefront builds the body inertias and their composites, 0 = the dynamics side */
+#endif
+#ifndef PF_DUAL_CREG
+#define PF_DUAL_CREG 4     /* DUAL instances: contact rows / joint-limit rows the PGS sweep keeps in registers (128 VGPRs) */
+#endif
+#ifndef PF_DUAL_LREG
+#define PF_DUAL_LREG 2
+#endif
 #define PF_KSPH 24         /* collision spheres staged per robot (PointFoot instance; the quadruped instance uses 32) */
 #define PF_KSPH_QUAD 32
 #define PF_KPAIR_QUAD 56      /* self-collision capsule pairs of the quadruped instance built with it (4 legs x {thigh, shank, foot}: 54) */
@@ -202,16 +212,26 @@ struct PfStepArgs {
 // KPR: self-collision capsule pairs the instance is built for (0: built without self-collision)
 // NBD: bodies of the model the dynamics run on -- the robot with its fixed-joint bodies (the feet) lumped into their parents
 // (pf_lump.h); NB stays the number of bodies the record reports on (contact_forces, feet)
-template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0), int NBD = NB>
+// DUAL_: two wavefronts per robot group (GPU only; the host build runs the two roles one after the other): wave 0 runs the
+// dynamics of a substep (kinematics with velocities, inertias, mass matrix, factorisation), wave 1 -- at the same time -- its
+// contact side (kinematics without velocities, collision queries, candidate compaction, contact rows); they meet before the
+// constraint solves.  The launch is one wavefront's dependent chain: the chain gets shorter, not the work.
+template <int NB, int ND, int NF, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0), int NBD = NB, bool DUAL_ = false>
 struct PfKernel {
+#if defined(PF_HOST_EMU)
+  static constexpr bool DUAL = false;
+#else
+  static constexpr bool DUAL = DUAL_;
+#endif
   static constexpr int PF_W = 64 / RPW;         // lanes per robot (pf_simt.h)
   static constexpr bool LR = KIND == PF_KIND_LEGGED_ROBOT;      // LeggedRobot / Anymal semantics (legged_robot.py)
-  static constexpr bool PF_OPAQUE_LANE = LR;                    // pf_simt.h: no hoisting of lane-derived values (register pressure)
+  static constexpr bool PF_OPAQUE_LANE = LR || DUAL;                  // pf_simt.h: no hoisting of lane-derived values (register pressure)
   static constexpr int REC_MAX = LR ? 704 : PF_REC_MAX;
   static constexpr int NV = 6 + ND;
   static constexpr int NVP = NV | 1;          // odd row stride: per-lane rows hit distinct LDS banks
   static constexpr int MAXC = LR ? PF_MAXC_QUAD : PF_MAXC;
-  static constexpr int CREG = MAXC < 6 ? MAXC : 6;      // contact rows the PGS sweep holds in registers; the rest stay in LDS
+  // contact rows the PGS sweep holds in registers; the rest stay in LDS (a DUAL instance has 128 VGPRs: four -- a biped rarely has more)
+  static constexpr int CREG = DUAL_ ? PF_DUAL_CREG : (MAXC < 6 ? MAXC : 6);
   // self-collision capsules / capsule pairs this instance is built for (PointFoot: 2 legs x 4 links = 8 / 16; a quadruped with
   // self-collision: 4 legs x {thigh, shank, foot} = 12 / 54, anymal_c_flat_config.py:42; anymal_c_rough switches it off,
   // anymal_c_rough_config.py:77, and runs the instance built without)
@@ -227,7 +247,8 @@ struct PfKernel {
 #else
   // <= 12 velocity components: the Cholesky factor lives in registers (packed lower triangle, every lane holds all of it
   // and factorises redundantly with static indices: no LDS round trips, no barriers), and the substitutions read it there
-  static constexpr bool CHOLR = NV <= 12;
+  // (DUAL instances run four wavefronts per SIMD: 128 VGPRs -- the packed triangle does not fit; see CHOLD)
+  static constexpr bool CHOLR = NV <= 12 && !DUAL;
 #endif
 #if defined(PF_HOST_EMU)
   static constexpr bool CHOLL = false;
@@ -236,8 +257,28 @@ struct PfKernel {
   // other lanes through v_readlane (wave-uniform SGPR operands) -- no LDS traffic or barriers during the factorisation
   static constexpr bool CHOLL = !CHOLR && RPW == 1 && NV <= 32;
 #endif
-  static constexpr int NLT = CHOLR ? NV * (NV + 1) / 2 : 1;
+#if defined(PF_HOST_EMU)
+  static constexpr bool CHOLD = false;
+#else
+  // DUAL instances, <= 16 velocity components: the factor is DISTRIBUTED over the lanes of every 16-lane DPP row -- lane i holds row
+  // i (NV registers instead of NV (NV + 1) / 2 in every lane) and an entry of another row reaches a lane as the DPP operand of the
+  // multiply-add that consumes it (row_newbcast: lane n of the row to all 16).  Same operations in the same order as CHOLR: the
+  // factor and every solve come out bit for bit the same.  Every lane must be active wherever the factor is read (a DPP read
+  // of a lane that EXEC has switched off returns 0): the solves run unpredicated on clamped rows and predicate their stores.
+  static constexpr bool CHOLD = DUAL && NV <= 16;
+#endif
+  static constexpr int NLT = CHOLR ? NV * (NV + 1) / 2 : (CHOLD ? NV : 1);
   static constexpr int NDV = CHOLR ? NV : 1;
+#if !defined(PF_HOST_EMU)
+  // x as lane N of the 16-lane DPP row holds it (N static)
+  template <int N>
+  PF_DEV float row_bcast(float x) {
+    static_assert(N >= 0 && N < 16, "row_newbcast takes a lane of the row");
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + N, 0xF, 0xF, true));
+  }
+  // the static-index trampolines of the unrolled factorisation / substitutions
+  template <int I, int T> PF_DEV float chold_L(const float (&Lr)[NLT]) { return row_bcast<I>(Lr[CHOLD ? T : 0]); }      // L[I][T], T < I
+#endif
   static constexpr int lt(int i, int t) { return i * (i + 1) / 2 + t; }
 
 
@@ -355,21 +396,28 @@ struct PfKernel {
     float gates[LR ? ND * 32 : 1];            // LSTM gate pre-activations
     float Rw[NBD][9], r[NBD][3], ax[NBD][3];
     // The dynamics scratch (dead once the mass matrix and the bias are built) and the contact candidates (born after the
-    // factorisation, dead after the contact rows) share storage.
-    union {
-      struct {
-        float Sj[NBD][6], V[NBD][6], A[NBD][6];      // {ang, lin@O}
-        float I[NBD][10], Ic[NBD][10];
-        float f[NBD][6], fc[NBD][6];                // {moment@O, force}
-        float F[ND][6];
-      };
-      struct {
-        float sphc[KS][3];                        // sphere centres relative to the base origin
-        float cn[2 * KS][3], cd[2 * KS];          // normal / signed distance: floor candidate s at [s], face candidate at [KS + s]
-        float pn[KP][3], px[KP][3], pd[KP];       // capsule pairs: normal (b -> a), contact point, distance
-        int ccell[KS];                            // 4 * grid cell + face of the sphere's terrain query (diagnostic word)
-      };
+    // factorisation, dead after the contact rows) share storage when ONE wavefront runs both (union); with a wavefront for
+    // each side (DUAL) both are live at once, and the contact side has frames of its own (kb).
+    struct DynS {
+      float Sj[NBD][6], V[NBD][6], A[NBD][6];      // {ang, lin@O}
+      float I[NBD][10], Ic[NBD][10];
+      float f[NBD][6], fc[NBD][6];                // {moment@O, force}
+      float F[ND][6];
     };
+    struct ConS {
+      float sphc[KS][3];                        // sphere centres relative to the base origin
+      float cn[2 * KS][3], cd[2 * KS];          // normal / signed distance: floor candidate s at [s], face candidate at [KS + s]
+      float pn[KP][3], px[KP][3], pd[KP];       // capsule pairs: normal (b -> a), contact point, distance
+      int ccell[KS];                            // 4 * grid cell + face of the sphere's terrain query (diagnostic word)
+    };
+    union ScratchU { DynS d; ConS c; };
+    struct ScratchP { DynS d; ConS c; };
+    typename std::conditional<DUAL, ScratchP, ScratchU>::type u;
+    struct KinB { float Rw[NBD][9], r[NBD][3], ax[NBD][3]; };
+    struct None {};
+    typename std::conditional<DUAL, KinB, None>::type kb;      // the contact wavefront's own body frames (same arithmetic, same bits)
+    int ncon_x, anchor_x[2], flag_x; float hsum_x;             // handed from one wavefront to the other (DUAL)
+    float park_x[4];                                           // values of the step parked across the substep loop (DUAL: 128 VGPRs)
     float M[NV][NVP];
     float dinv[NV];
     float bias[NV], vel[NV], vold[NV];
@@ -380,10 +428,14 @@ struct PfKernel {
   };
   // the height scan (post-physics only) reuses the constraint-row storage (physics only)
   static_assert(NROWS * NVP >= PF_MAX_HPTS, "height scan does not fit the aliased row storage");
-  PF_DEV float* heights_of(Shared& sh) { return &sh.J[0][0]; }
+  // (a DUAL instance keeps both in its contact scratch -- dead once the last substep's rows are handed over --, where the partner
+  // wavefront fills them while the constraint-row storage is still in use)
+  static_assert(!DUAL || sizeof(typename Shared::ConS) >= 4 * (160 + PF_MAX_HPTS), "noise + height scratch does not fit the contact scratch");
+  PF_DEV float* heights_of(Shared& sh) { if constexpr (DUAL) return reinterpret_cast<float*>(&sh.u.c) + 160; else return &sh.J[0][0]; }
   // ... and the block-wise uniform draws of the observation noise reuse the other row array
   static_assert(NROWS * NVP >= 4 * (PF_MAX_OBS / 4 + 2), "noise scratch does not fit the aliased row storage");
-  PF_DEV float* noise_of(Shared& sh) { return &sh.W[0][0]; }
+  PF_DEV float* noise_of(Shared& sh) { if constexpr (DUAL) return reinterpret_cast<float*>(&sh.u.c); else return &sh.W[0][0]; }
+  static_assert(4 * ((27 + PF_MAX_HPTS) / 4 + 2) <= 4 * 160 || !DUAL, "noise scratch of a DUAL instance: 160 floats");
 
   // ------------------------------------------------------------------ terrain
   // point_foot.py:1100-1112 for one point; exact float32 op order of the reference, no FMA contraction
@@ -590,9 +642,15 @@ struct PfKernel {
   }
 
   // ------------------------------------------------------------------ forward kinematics (+ velocities)
-  template <bool WITH_VEL>
+  // body frames of the wavefront that runs the dynamics (sh.Rw / r / ax) or -- KB, DUAL instances only -- of the contact wavefront
+  template <bool KB> PF_DEV float (&Rw_of(Shared& sh))[NBD][9] { if constexpr (KB && DUAL) return sh.kb.Rw; else return sh.Rw; }
+  template <bool KB> PF_DEV float (&r_of(Shared& sh))[NBD][3] { if constexpr (KB && DUAL) return sh.kb.r; else return sh.r; }
+  template <bool KB> PF_DEV float (&ax_of(Shared& sh))[NBD][3] { if constexpr (KB && DUAL) return sh.kb.ax; else return sh.ax; }
+  template <bool WITH_VEL, bool KB = false>
   PF_DEV void kinematics(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L) {
+    static_assert(!(WITH_VEL && KB), "the contact wavefront needs positions only");
     const float* S = sh.rec;
+    float (&kRw)[NBD][9] = Rw_of<KB>(sh); float (&kr)[NBD][3] = r_of<KB>(sh); float (&kax)[NBD][3] = ax_of<KB>(sh);
     // base frame / velocity / bias acceleration: uniform (every lane needs them as the root of its chain)
     float R0[9], V0[6], A0[6];
     {
@@ -609,12 +667,12 @@ struct PfKernel {
     }
     PF_ONE {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) sh.Rw[0][t] = R0[t];
+      for (int t = 0; t < 9; ++t) kRw[0][t] = R0[t];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) { sh.r[0][t] = 0.0f; sh.ax[0][t] = 0.0f; }
+      for (int t = 0; t < 3; ++t) { kr[0][t] = 0.0f; kax[0][t] = 0.0f; }
       if (WITH_VEL) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t) { sh.V[0][t] = V0[t]; sh.A[0][t] = A0[t]; sh.Sj[0][t] = 0.0f; }
+        for (int t = 0; t < 6; ++t) { sh.u.d.V[0][t] = V0[t]; sh.u.d.A[0][t] = A0[t]; sh.u.d.Sj[0][t] = 0.0f; }
       }
     }
     // one lane per root-to-leaf chain: the parent's frame stays in registers, no barrier between tree levels.  (A level-
@@ -640,7 +698,7 @@ struct PfKernel {
         float jp[3] = {m.joint_pos[i][0], m.joint_pos[i][1], m.joint_pos[i][2]}, ro[3];
         pf_mat_vec(Rp, jp, ro);
         float ri[3] = {rp[0] + ro[0], rp[1] + ro[1], rp[2] + ro[2]};
-        sh.r[i][0] = ri[0]; sh.r[i][1] = ri[1]; sh.r[i][2] = ri[2];
+        kr[i][0] = ri[0]; kr[i][1] = ri[1]; kr[i][2] = ri[2];
         const int k = m.dof_of_body[i];
         if (k >= 0) {
           float a[3] = {m.joint_axis[i][0], m.joint_axis[i][1], m.joint_axis[i][2]};
@@ -652,13 +710,13 @@ struct PfKernel {
                          t1 * a[0] * a[1] + sn * a[2], t1 * a[1] * a[1] + cs, t1 * a[1] * a[2] - sn * a[0],
                          t1 * a[0] * a[2] - sn * a[1], t1 * a[1] * a[2] + sn * a[0], t1 * a[2] * a[2] + cs};
           pf_mat_mul(Rj, Ra, Rp);
-          sh.ax[i][0] = aw[0]; sh.ax[i][1] = aw[1]; sh.ax[i][2] = aw[2];
+          kax[i][0] = aw[0]; kax[i][1] = aw[1]; kax[i][2] = aw[2];
           if (WITH_VEL) {
             float sl[3]; pf_cross(ri, aw, sl);
             float qd = S[LC::dof_vel + k];
             float Vi[6];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) { sh.Sj[i][t] = aw[t]; sh.Sj[i][3 + t] = sl[t]; Vi[t] = Vp[t] + qd * aw[t]; Vi[3 + t] = Vp[3 + t] + qd * sl[t]; }
+            for (int t = 0; t < 3; ++t) { sh.u.d.Sj[i][t] = aw[t]; sh.u.d.Sj[i][3 + t] = sl[t]; Vi[t] = Vp[t] + qd * aw[t]; Vi[3 + t] = Vp[3 + t] + qd * sl[t]; }
             float ca[3], c1[3], c2[3];
             pf_cross(Vi, aw, ca); pf_cross(Vi, sl, c1); pf_cross(Vi + 3, aw, c2);
 #pragma unroll
@@ -669,17 +727,17 @@ struct PfKernel {
         } else {
 #pragma unroll
           for (int t = 0; t < 9; ++t) Rp[t] = Rj[t];
-          sh.ax[i][0] = 0.0f; sh.ax[i][1] = 0.0f; sh.ax[i][2] = 0.0f;
+          kax[i][0] = 0.0f; kax[i][1] = 0.0f; kax[i][2] = 0.0f;
           if (WITH_VEL) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) sh.Sj[i][t] = 0.0f;
+            for (int t = 0; t < 6; ++t) sh.u.d.Sj[i][t] = 0.0f;
           }
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) sh.Rw[i][t] = Rp[t];
+        for (int t = 0; t < 9; ++t) kRw[i][t] = Rp[t];
         if (WITH_VEL) {
 #pragma unroll
-          for (int t = 0; t < 6; ++t) { sh.V[i][t] = Vp[t]; sh.A[i][t] = Ap[t]; }
+          for (int t = 0; t < 6; ++t) { sh.u.d.V[i][t] = Vp[t]; sh.u.d.A[i][t] = Ap[t]; }
         }
         rp[0] = ri[0]; rp[1] = ri[1]; rp[2] = ri[2];
       }
@@ -688,71 +746,59 @@ struct PfKernel {
   }
 
   // ------------------------------------------------------------------ one physics substep of sim_dt
-  PF_DEV void substep(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, bool apply_ext, int env, int sub, int ix0, int iy0) {
-    float* S = sh.rec;
-    const float dt = c.sim_dt;
-    kinematics<true>(sh, m, c, L);
-    PF_STAMP(sh, 1);
-    // ---- per-body spatial inertia about O and bias wrench
-    PF_LANES(i, NBD) {
-      float mass = m.mass[i];
-      float cl[3] = {m.com[i][0], m.com[i][1], m.com[i][2]};
-      float Il[6];
-      for (int t = 0; t < 6; ++t) Il[t] = m.inertia[i][t];
-      if (i == 0) {   // base mass / COM randomisation (:466-477), inertia scaled with mass
-        float added = S[LC::added_mass];
-        float sc = (mass + added) / mass;
-        mass += added;
-        for (int t = 0; t < 3; ++t) cl[t] += S[LC::added_com + t];
-        for (int t = 0; t < 6; ++t) Il[t] *= sc;
-      }
-      const float* R = sh.Rw[i];
-      float cw[3]; pf_mat_vec(R, cl, cw);
-      for (int t = 0; t < 3; ++t) cw[t] += sh.r[i][t];
-      float Ilm[9] = {Il[0], Il[3], Il[4], Il[3], Il[1], Il[5], Il[4], Il[5], Il[2]};
-      float T[9]; pf_mat_mul(R, Ilm, T);
-      float Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
-      float Iw[9]; pf_mat_mul(T, Rt, Iw);
-      float c2 = pf_dot3(cw, cw);
-      float I10[10];
-      I10[0] = mass; I10[1] = mass * cw[0]; I10[2] = mass * cw[1]; I10[3] = mass * cw[2];
-      I10[4] = Iw[0] + mass * (c2 - cw[0] * cw[0]);
-      I10[5] = Iw[4] + mass * (c2 - cw[1] * cw[1]);
-      I10[6] = Iw[8] + mass * (c2 - cw[2] * cw[2]);
-      I10[7] = Iw[1] - mass * cw[0] * cw[1];
-      I10[8] = Iw[2] - mass * cw[0] * cw[2];
-      I10[9] = Iw[5] - mass * cw[1] * cw[2];
-      for (int t = 0; t < 10; ++t) sh.I[i][t] = I10[t];
-      float Vi[6], Ai[6], IA[6], IV[6];
-      for (int t = 0; t < 6; ++t) { Vi[t] = sh.V[i][t]; Ai[t] = sh.A[i][t]; }
-      pf_spI_mul(I10, Ai, IA); pf_spI_mul(I10, Vi, IV);
-      float x1[3], x2[3], x3[3];
-      pf_cross(Vi, IV, x1); pf_cross(Vi + 3, IV + 3, x2); pf_cross(Vi, IV + 3, x3);
-      for (int t = 0; t < 3; ++t) { sh.f[i][t] = IA[t] + x1[t] + x2[t]; sh.f[i][3 + t] = IA[3 + t] + x3[t]; }
-      if (i == 0 && apply_ext)
-        for (int t = 0; t < 3; ++t) sh.f[0][3 + t] -= S[LC::ext_force + t];
+  // ---- spatial inertia of body i about O (world axes), from its frame (KB: the contact wavefront's own frames): I10 and sh.u.d.I[i]
+  template <bool KB>
+  PF_DEV void body_inertia(Shared& sh, const ModelS& m, int i, float (&I10)[10]) {
+    const float* S = sh.rec;
+    float mass = m.mass[i];
+    float cl[3] = {m.com[i][0], m.com[i][1], m.com[i][2]};
+    float Il[6];
+    for (int t = 0; t < 6; ++t) Il[t] = m.inertia[i][t];
+    if (i == 0) {   // base mass / COM randomisation (:466-477), inertia scaled with mass
+      float added = S[LC::added_mass];
+      float sc = (mass + added) / mass;
+      mass += added;
+      for (int t = 0; t < 3; ++t) cl[t] += S[LC::added_com + t];
+      for (int t = 0; t < 6; ++t) Il[t] *= sc;
     }
-    PF_SYNC();
-    // ---- composites over DFS-contiguous subtrees: one lane per (body, component)
-    PF_LANES(e, NBD * 16) {
-      int i = e >> 4, t = e & 15;
+    const float* R = Rw_of<KB>(sh)[i];
+    float cw[3]; pf_mat_vec(R, cl, cw);
+    for (int t = 0; t < 3; ++t) cw[t] += r_of<KB>(sh)[i][t];
+    float Ilm[9] = {Il[0], Il[3], Il[4], Il[3], Il[1], Il[5], Il[4], Il[5], Il[2]};
+    float T[9]; pf_mat_mul(R, Ilm, T);
+    float Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+    float Iw[9]; pf_mat_mul(T, Rt, Iw);
+    float c2 = pf_dot3(cw, cw);
+    I10[0] = mass; I10[1] = mass * cw[0]; I10[2] = mass * cw[1]; I10[3] = mass * cw[2];
+    I10[4] = Iw[0] + mass * (c2 - cw[0] * cw[0]);
+    I10[5] = Iw[4] + mass * (c2 - cw[1] * cw[1]);
+    I10[6] = Iw[8] + mass * (c2 - cw[2] * cw[2]);
+    I10[7] = Iw[1] - mass * cw[0] * cw[1];
+    I10[8] = Iw[2] - mass * cw[0] * cw[2];
+    I10[9] = Iw[5] - mass * cw[1] * cw[2];
+    for (int t = 0; t < 10; ++t) sh.u.d.I[i][t] = I10[t];
+  }
+  // composite inertias / composite bias wrenches alone (the two halves of the composite pass; same sums, same order)
+  PF_DEV void composite_inertias(Shared& sh, const ModelS& m) {
+    PF_LANES(e, NBD * 10) {
+      int i = e / 10, t = e - 10 * i;
       int end = i + m.subtree[i];
       float acc = 0.0f;
-      if (t < 10) { for (int j = i; j < end; ++j) acc += sh.I[j][t]; sh.Ic[i][t] = acc; }
-      else { for (int j = i; j < end; ++j) acc += sh.f[j][t - 10]; sh.fc[i][t - 10] = acc; }
+      for (int j = i; j < end; ++j) acc += sh.u.d.I[j][t];
+      sh.u.d.Ic[i][t] = acc;
     }
-    PF_SYNC();
-    PF_LANES(k, ND) {
-      int i = m.body_of_dof[k];
-      float Ic[10], Sv[6], Fo[6];
-      for (int t = 0; t < 10; ++t) Ic[t] = sh.Ic[i][t];
-      for (int t = 0; t < 6; ++t) Sv[t] = sh.Sj[i][t];
-      pf_spI_mul(Ic, Sv, Fo);
-      for (int t = 0; t < 6; ++t) sh.F[k][t] = Fo[t];
+  }
+  PF_DEV void composite_wrenches(Shared& sh, const ModelS& m) {
+    PF_LANES(e, NBD * 6) {
+      int i = e / 6, t = e - 6 * i;
+      int end = i + m.subtree[i];
+      float acc = 0.0f;
+      for (int j = i; j < end; ++j) acc += sh.u.d.f[j][t];
+      sh.u.d.fc[i][t] = acc;
     }
-    PF_SYNC();
-    PF_STAMP(sh, 2);
-    // ---- mass matrix (lower triangle; generalised velocity [v_O, w, qd]) + bias + old velocity
+  }
+  // ---- mass matrix entries (packed lower triangle) from the composite inertias, F and the joint motion subspaces
+  PF_DEV void mass_entries(Shared& sh, const ModelS& m) {
     PF_LANES(e, NV * (NV + 1) / 2) {      // entry e of the packed lower triangle: row a = largest a with a (a + 1) / 2 <= e
       int a = (int)((pf_sqrt(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
       a += ((a + 1) * (a + 2) / 2 <= e) ? 1 : 0;      // (the square root may be an ulp off at the row starts)
@@ -760,7 +806,7 @@ struct PfKernel {
       const int b = e - a * (a + 1) / 2;
       float v = 0.0f;
       if (a < 6) {
-        const float* C = sh.Ic[0];
+        const float* C = sh.u.d.Ic[0];
         if (a < 3) v = (a == b) ? C[0] : 0.0f;
         else if (b >= 3) {
           int x = a - 3, y = b - 3;
@@ -774,34 +820,18 @@ struct PfKernel {
         }
       } else {
         int ka = a - 6;
-        if (b < 6) v = b < 3 ? sh.F[ka][3 + b] : sh.F[ka][b - 3];
+        if (b < 6) v = b < 3 ? sh.u.d.F[ka][3 + b] : sh.u.d.F[ka][b - 3];
         else {
           int kb = b - 6, ia = m.body_of_dof[ka], ib = m.body_of_dof[kb];
-          if (ib <= ia && ia < ib + m.subtree[ib]) v = pf_dot3(sh.Sj[ib], sh.F[ka]) + pf_dot3(sh.Sj[ib] + 3, sh.F[ka] + 3);
-          else if (ia <= ib && ib < ia + m.subtree[ia]) v = pf_dot3(sh.Sj[ia], sh.F[kb]) + pf_dot3(sh.Sj[ia] + 3, sh.F[kb] + 3);
+          if (ib <= ia && ia < ib + m.subtree[ib]) v = pf_dot3(sh.u.d.Sj[ib], sh.u.d.F[ka]) + pf_dot3(sh.u.d.Sj[ib] + 3, sh.u.d.F[ka] + 3);
+          else if (ia <= ib && ib < ia + m.subtree[ia]) v = pf_dot3(sh.u.d.Sj[ia], sh.u.d.F[kb]) + pf_dot3(sh.u.d.Sj[ia] + 3, sh.u.d.F[kb] + 3);
         }
       }
       sh.M[a][b] = v;
     }
-    PF_LANES(a, NV) {
-      float bv, vo;
-      if (a < 3) { bv = sh.fc[0][3 + a]; vo = S[LC::root + 7 + a]; }
-      else if (a < 6) { bv = sh.fc[0][a - 3]; vo = S[LC::root + 7 + a]; }
-      else {
-        int k = a - 6, i = m.body_of_dof[k];
-        bv = pf_dot3(sh.Sj[i], sh.fc[i]) + pf_dot3(sh.Sj[i] + 3, sh.fc[i] + 3);
-        vo = S[LC::dof_vel + k];
-      }
-      sh.bias[a] = bv; sh.vold[a] = vo;
-      float rhs = -bv + (a >= 6 ? S[LC::torques + a - 6] : 0.0f);
-      if (B.d_joint_friction && a >= 6)     // regularised Coulomb joint friction (update_frictions, :103-108)
-        rhs -= B.d_joint_friction[(size_t)env * ND + a - 6] * pf_clip(vo * pf_rcp(c.joint_friction_vel), -1.0f, 1.0f);
-      sh.J[RFREE][a] = rhs; sh.W[RFREE][a] = rhs;
-    }
-    PF_SYNC();
-    PF_STAMP(sh, 3);
-    // ---- Cholesky (same operation order in both forms)
-    float Lr[NLT], dv[NDV];
+  }
+  // ---- Cholesky factor of sh.M into registers (Lr / dv; CHOLL, LDS forms: in place in sh.M / sh.dinv)
+  PF_DEV void factorise(Shared& sh, float (&Lr)[NLT], float (&dv)[NDV]) {
     if constexpr (CHOLR) {
 #pragma unroll
       for (int i = 0; i < NV; ++i)
@@ -823,6 +853,15 @@ struct PfKernel {
           Lr[lt(i, j)] = sacc * di;
         }
       }
+    } else if constexpr (CHOLD) {
+#if !defined(PF_HOST_EMU)
+      const int li = PF_LANE_ID & 15;
+#pragma unroll
+      for (int t = 0; t < NV; ++t) Lr[t] = (li < NV && t <= li) ? sh.M[li < NV ? li : 0][t] : 0.0f;
+      float mydi = 0.0f;
+      chold_factor<0>(Lr, mydi, li);
+      dv[0] = mydi;
+#endif
     } else if constexpr (CHOLL) {
 #if !defined(PF_HOST_EMU)
       const int li = PF_LANE_ID;
@@ -868,23 +907,104 @@ struct PfKernel {
         PF_SYNC();
       }
     }
+  }
+  // One substep = three parts: (1) the dynamics side, (2) the contact side, (3) constraint solves + integration.  (1) and (2) are
+  // independent of each other; a DUAL instance runs them on two wavefronts at once (run()), everything else one after the other.
+  PF_DEV void substep(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, bool apply_ext, int env, int sub, int ix0, int iy0) {
+    float Lr[NLT], dv[NDV];
+    substep_dyn(sh, m, c, L, B, apply_ext, env, Lr, dv);
+    const int ncon = substep_contacts<false>(sh, m, c, L, B, env, sub, ix0, iy0);
+    substep_solve(sh, m, c, L, B, env, sub, ncon, Lr, dv);
+  }
+  // (1) kinematics with velocities, per-body inertias and bias wrenches, composites, mass matrix + bias, Cholesky factor (Lr / dv)
+  PF_DEV void substep_dyn(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, bool apply_ext, int env, float (&Lr)[NLT], float (&dv)[NDV], int handoff = 0) {
+    float* S = sh.rec;
+    kinematics<true>(sh, m, c, L);
+    PF_STAMP(sh, 1);
+    // ---- per-body spatial inertia about O and bias wrench
+    // (DUAL: inertias and their composites are position-only -- the partner wavefront builds them, run(), and flags them)
+    if constexpr (DUAL && PF_DUAL_INERTIA) PF_HANDOFF_WAIT(sh.flag_x, handoff);
+    PF_LANES(i, NBD) {
+      float I10[10];
+      if constexpr (DUAL && PF_DUAL_INERTIA) { for (int t = 0; t < 10; ++t) I10[t] = sh.u.d.I[i][t]; }
+      else body_inertia<false>(sh, m, i, I10);
+      float Vi[6], Ai[6], IA[6], IV[6];
+      for (int t = 0; t < 6; ++t) { Vi[t] = sh.u.d.V[i][t]; Ai[t] = sh.u.d.A[i][t]; }
+      pf_spI_mul(I10, Ai, IA); pf_spI_mul(I10, Vi, IV);
+      float x1[3], x2[3], x3[3];
+      pf_cross(Vi, IV, x1); pf_cross(Vi + 3, IV + 3, x2); pf_cross(Vi, IV + 3, x3);
+      for (int t = 0; t < 3; ++t) { sh.u.d.f[i][t] = IA[t] + x1[t] + x2[t]; sh.u.d.f[i][3 + t] = IA[3 + t] + x3[t]; }
+      if (i == 0 && apply_ext)
+        for (int t = 0; t < 3; ++t) sh.u.d.f[0][3 + t] -= S[LC::ext_force + t];
+    }
+    PF_SYNC();
+    // ---- composites over DFS-contiguous subtrees: one lane per (body, component)
+    if constexpr (DUAL && PF_DUAL_INERTIA) composite_wrenches(sh, m);
+    else {
+      PF_LANES(e, NBD * 16) {
+        int i = e >> 4, t = e & 15;
+        int end = i + m.subtree[i];
+        float acc = 0.0f;
+        if (t < 10) { for (int j = i; j < end; ++j) acc += sh.u.d.I[j][t]; sh.u.d.Ic[i][t] = acc; }
+        else { for (int j = i; j < end; ++j) acc += sh.u.d.f[j][t - 10]; sh.u.d.fc[i][t - 10] = acc; }
+      }
+    }
+    PF_SYNC();
+    PF_LANES(k, ND) {
+      int i = m.body_of_dof[k];
+      float Ic[10], Sv[6], Fo[6];
+      for (int t = 0; t < 10; ++t) Ic[t] = sh.u.d.Ic[i][t];
+      for (int t = 0; t < 6; ++t) Sv[t] = sh.u.d.Sj[i][t];
+      pf_spI_mul(Ic, Sv, Fo);
+      for (int t = 0; t < 6; ++t) sh.u.d.F[k][t] = Fo[t];
+    }
+    PF_SYNC();
+    PF_STAMP(sh, 2);
+    // ---- mass matrix (lower triangle; generalised velocity [v_O, w, qd]) + bias + old velocity
+    mass_entries(sh, m);
+    PF_LANES(a, NV) {
+      float bv, vo;
+      if (a < 3) { bv = sh.u.d.fc[0][3 + a]; vo = S[LC::root + 7 + a]; }
+      else if (a < 6) { bv = sh.u.d.fc[0][a - 3]; vo = S[LC::root + 7 + a]; }
+      else {
+        int k = a - 6, i = m.body_of_dof[k];
+        bv = pf_dot3(sh.u.d.Sj[i], sh.u.d.fc[i]) + pf_dot3(sh.u.d.Sj[i] + 3, sh.u.d.fc[i] + 3);
+        vo = S[LC::dof_vel + k];
+      }
+      sh.bias[a] = bv; sh.vold[a] = vo;
+      float rhs = -bv + (a >= 6 ? S[LC::torques + a - 6] : 0.0f);
+      if (B.d_joint_friction && a >= 6)     // regularised Coulomb joint friction (update_frictions, :103-108)
+        rhs -= B.d_joint_friction[(size_t)env * ND + a - 6] * pf_clip(vo * pf_rcp(c.joint_friction_vel), -1.0f, 1.0f);
+      sh.J[RFREE][a] = rhs; sh.W[RFREE][a] = rhs;
+    }
+    PF_SYNC();
+    PF_STAMP(sh, 3);
+    factorise(sh, Lr, dv);
     PF_STAMP(sh, 4);
+  }
+  // (2) contact candidates, compaction, contact rows (Jacobians and targets).  KB: on the contact wavefront's own body frames.
+  // Returns the number of contacts kept.
+  template <bool KB>
+  PF_DEV int substep_contacts(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, int env, int sub, int ix0, int iy0) {
+    float* S = sh.rec;
+    const float dt = c.sim_dt;
+    float (&kRw)[NBD][9] = Rw_of<KB>(sh); float (&kr)[NBD][3] = r_of<KB>(sh); float (&kax)[NBD][3] = ax_of<KB>(sh);
     // ---- contact candidates, in a fixed order: floor contact of sphere s (candidate s), vertical-face contact of sphere s
     //      (nsph + s), self-collision capsule pair p (2 nsph + p); the first MAXC active ones are kept
     const int16_t* hs = B.d_height_samples;
     const int nsph = m.nsph;
     PF_LANES(s, nsph) {
       int i = m.sph_body[s];
-      float xs[3]; pf_mat_vec(sh.Rw[i], m.sph_pos[s], xs);
-      for (int t = 0; t < 3; ++t) xs[t] += sh.r[i][t];
+      float xs[3]; pf_mat_vec(kRw[i], m.sph_pos[s], xs);
+      for (int t = 0; t < 3; ++t) xs[t] += kr[i][t];
       float h, n[3], wn[3], wd;
       int cellface;
       float rad = m.sph_radius[s];
       terrain_query(c, hs, ix0, iy0, S[LC::root] + xs[0], S[LC::root + 1] + xs[1], S[LC::root + 2] + xs[2], rad, &h, n, wn, &wd, &cellface);
-      sh.ccell[s] = cellface;
-      sh.cd[s] = (S[LC::root + 2] + xs[2] - h) * n[2] - rad;
-      sh.cd[KS + s] = wd;
-      for (int t = 0; t < 3; ++t) { sh.sphc[s][t] = xs[t]; sh.cn[s][t] = n[t]; sh.cn[KS + s][t] = wn[t]; }
+      sh.u.c.ccell[s] = cellface;
+      sh.u.c.cd[s] = (S[LC::root + 2] + xs[2] - h) * n[2] - rad;
+      sh.u.c.cd[KS + s] = wd;
+      for (int t = 0; t < 3; ++t) { sh.u.c.sphc[s][t] = xs[t]; sh.u.c.cn[s][t] = n[t]; sh.u.c.cn[KS + s][t] = wn[t]; }
     }
     PF_SYNC();
     int npair = 0;
@@ -895,10 +1015,10 @@ struct PfKernel {
         const int a0 = m.cap_s0[ca], b0 = m.cap_s0[cb];
         // capsules whose midpoints are further apart than their reach cannot be within contact_offset: the closest-point
         // computation is skipped (by the whole wavefront when no pair of its robots is near -- the usual case)
-        const float *pa0 = sh.sphc[a0], *pa1 = sh.sphc[m.cap_s1[ca]], *pb0 = sh.sphc[b0], *pb1 = sh.sphc[m.cap_s1[cb]];
+        const float *pa0 = sh.u.c.sphc[a0], *pa1 = sh.u.c.sphc[m.cap_s1[ca]], *pb0 = sh.u.c.sphc[b0], *pb1 = sh.u.c.sphc[m.cap_s1[cb]];
         const float mx = 0.5f * ((pa0[0] + pa1[0]) - (pb0[0] + pb1[0])), my = 0.5f * ((pa0[1] + pa1[1]) - (pb0[1] + pb1[1])), mz = 0.5f * ((pa0[2] + pa1[2]) - (pb0[2] + pb1[2]));
         const float lim = m.pair_reach[p] + c.contact_offset;
-        if (mx * mx + my * my + mz * mz > lim * lim) { sh.pd[p] = 1e9f; continue; }
+        if (mx * mx + my * my + mz * mz > lim * lim) { sh.u.c.pd[p] = 1e9f; continue; }
         float v[3], c2[3];
         segment_segment(pa0, pa1, pb0, pb1, v, c2);
         const float len = pf_sqrt(pf_dot3(v, v)), rb = m.sph_radius[b0];
@@ -906,13 +1026,13 @@ struct PfKernel {
         const bool ok = len > 1e-9f;
         const float il = pf_rcp(fmaxf(len, 1e-9f));
         float n[3] = {ok ? v[0] * il : 0.0f, ok ? v[1] * il : 1.0f, ok ? v[2] * il : 0.0f};
-        sh.pd[p] = dist;
-        for (int t = 0; t < 3; ++t) { sh.pn[p][t] = n[t]; sh.px[p][t] = c2[t] + (rb + 0.5f * dist) * n[t]; }
+        sh.u.c.pd[p] = dist;
+        for (int t = 0; t < 3; ++t) { sh.u.c.pn[p][t] = n[t]; sh.u.c.px[p][t] = c2[t] + (rb + 0.5f * dist) * n[t]; }
       }
       PF_SYNC();
     }
     const int ncand = 2 * nsph + npair;
-    auto cand_dist = [&](int cand) { return cand < nsph ? sh.cd[cand] : (cand < 2 * nsph ? sh.cd[KS + cand - nsph] : sh.pd[SELF ? cand - 2 * nsph : 0]); };
+    auto cand_dist = [&](int cand) { return cand < nsph ? sh.u.c.cd[cand] : (cand < 2 * nsph ? sh.u.c.cd[KS + cand - nsph] : sh.u.c.pd[SELF ? cand - 2 * nsph : 0]); };
     int ncon = 0;
     unsigned long long cset[NCW];      // candidates 0..63 (/ 64..127) -- diagnostic output only
 #pragma unroll
@@ -954,7 +1074,7 @@ struct PfKernel {
       unsigned long long cells = 0ull;
       for (int ci = 0; ci < ncon; ++ci) {
         const int cand = sh.con_cand[ci];
-        if (cand < 2 * nsph) { const int cf = sh.ccell[cand < nsph ? cand : cand - nsph]; cells += (unsigned long long)(cand + 1) * (unsigned long long)(cand < nsph ? (cf & ~3) : cf); }
+        if (cand < 2 * nsph) { const int cf = sh.u.c.ccell[cand < nsph ? cand : cand - nsph]; cells += (unsigned long long)(cand + 1) * (unsigned long long)(cand < nsph ? (cf & ~3) : cf); }
       }
       PF_ONE {
         uint64_t* o = B.d_contact_set + ((size_t)env * c.decimation + sub) * PF_CSET_WORDS;
@@ -974,14 +1094,14 @@ struct PfKernel {
         const int s = cand < nsph ? cand : cand - nsph, slot = cand < nsph ? cand : KS + s;
         i = m.sph_body[s]; irep = m.sph_rep[s];
         const float rad = m.sph_radius[s];
-        dist = sh.cd[slot];
-        for (int t = 0; t < 3; ++t) { n[t] = sh.cn[slot][t]; xc[t] = sh.sphc[s][t] - rad * n[t]; }
+        dist = sh.u.c.cd[slot];
+        for (int t = 0; t < 3; ++t) { n[t] = sh.u.c.cn[slot][t]; xc[t] = sh.u.c.sphc[s][t] - rad * n[t]; }
       } else {
         const int p = SELF ? cand - 2 * nsph : 0;
         i = m.sph_body[m.cap_s0[m.pair_a[p]]]; ib = m.sph_body[m.cap_s0[m.pair_b[p]]];
         irep = m.sph_rep[m.cap_s0[m.pair_a[p]]]; ibrep = m.sph_rep[m.cap_s0[m.pair_b[p]]];
-        dist = sh.pd[p];
-        for (int t = 0; t < 3; ++t) { n[t] = sh.pn[p][t]; xc[t] = sh.px[p][t]; }
+        dist = sh.u.c.pd[p];
+        for (int t = 0; t < 3; ++t) { n[t] = sh.u.c.pn[p][t]; xc[t] = sh.u.c.px[p][t]; }
       }
       float ref[3] = {fabsf(n[0]) < 0.9f ? 1.0f : 0.0f, fabsf(n[0]) < 0.9f ? 0.0f : 1.0f, 0.0f};
       float t1[3]; pf_cross(n, ref, t1);
@@ -1006,14 +1126,16 @@ struct PfKernel {
         float sg = (j <= i && i < j + m.subtree[j]) ? 1.0f : 0.0f;
         if (SELF) sg -= (j <= ib && ib < j + m.subtree[j]) ? 1.0f : 0.0f;
         if (sg != 0.0f) {
-          float rel[3] = {xc[0] - sh.r[j][0], xc[1] - sh.r[j][1], xc[2] - sh.r[j][2]};
+          float rel[3] = {xc[0] - kr[j][0], xc[1] - kr[j][1], xc[2] - kr[j][2]};
           float cr[3]; pf_cross(rel, dd, cr);
-          row[6 + k] = sg * pf_dot3(sh.ax[j], cr);
+          row[6 + k] = sg * pf_dot3(kax[j], cr);
         }
       }
       float un0 = 0.0f;
 #pragma unroll
-      for (int a = 0; a < NV; ++a) { sh.J[rr][a] = row[a]; sh.W[rr][a] = row[a]; un0 += row[a] * sh.vold[a]; }
+      for (int a = 0; a < NV; ++a) {      // (the velocity before the substep, as the dynamics side copies it into sh.vold)
+        sh.J[rr][a] = row[a]; sh.W[rr][a] = row[a]; un0 += row[a] * (a < 6 ? S[LC::root + 7 + a] : S[LC::dof_vel + (a < 6 ? 0 : a - 6)]);
+      }
       float bn = 0.0f;
       if (d == 0) {
         const float idt = pf_rcp(dt);
@@ -1024,6 +1146,12 @@ struct PfKernel {
     }
     PF_SYNC();
     PF_STAMP(sh, 6);
+    return ncon;
+  }
+  // (3) W = M^-1 J^T, free velocity, joint-limit rows, Delassus blocks, projected Gauss-Seidel, integration, contact forces
+  PF_DEV void substep_solve(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, int env, int sub, int ncon, const float (&Lr)[NLT], const float (&dv)[NDV]) {
+    float* S = sh.rec;
+    const float dt = c.sim_dt;
     solve_rows(sh, 3 * ncon, true, Lr, dv);
     PF_SYNC();
     PF_STAMP(sh, 7);
@@ -1091,7 +1219,7 @@ struct PfKernel {
       // joint-limit rows: the first LREG live in registers like the contact rows; the 12-DOF instance keeps the rest in LDS
       // (J = +-e_k is rebuilt from lim_dof / lim_side, W and the impulse are read where they lie) -- 24 VGPRs the
       // quadruped kernel does not have (ANYmal's joints are continuous: no limit row is ever active there)
-      constexpr int LREG = ND <= 6 ? ND : 4;
+      constexpr int LREG = DUAL ? PF_DUAL_LREG : (ND <= 6 ? ND : 4);
       float jc[CREG][3], wc[CREG][3], lc[CREG][3], jl[LREG], wl[LREG], ll[LREG];
 #pragma unroll
       for (int ci = 0; ci < CREG; ++ci)
@@ -1267,39 +1395,118 @@ struct PfKernel {
     PF_STAMP(sh, 11);
   }
 
+#if !defined(PF_HOST_EMU)
+  // column J of the distributed factorisation (CHOLD), columns J + 1 .. by recursion, right-looking: the pivot leaves lane J by
+  // broadcast, every row below scales its entry of column J, and every remaining entry (i, k), J < k <= i, takes its update
+  // -L[i][J] L[k][J] at once -- NV - 1 - J independent multiply-adds per lane and column (the left-looking form is one dependent
+  // chain per entry).  Every entry still receives its updates in the order J = 0, 1, ..: the same sums, bit for bit, as CHOLR.
+  template <int J>
+  PF_DEV void chold_factor(float (&Lr)[NLT], float& mydi, int li) {
+    if constexpr (CHOLD && J < NV) {
+      float d = row_bcast<J>(Lr[J]);
+      d = pf_sqrt(fmaxf(d, 1e-12f));
+      const float di = pf_rcp(d);
+      const float lij = Lr[J] * di;               // L[li][J] for the rows below the pivot
+      Lr[J] = li > J ? lij : Lr[J];
+      mydi = li == J ? di : mydi;
+      chold_update<J, J + 1>(Lr, li);
+      chold_factor<J + 1>(Lr, mydi, li);
+    }
+  }
+  // A[li][K] -= L[li][J] * L[K][J] for K = K0 .. NV - 1 (entries of this lane's row right of column J, up to its diagonal)
+  template <int J, int K0>
+  PF_DEV void chold_update(float (&Lr)[NLT], int li) {
+    if constexpr (CHOLD && K0 < NV) {
+      const float upd = Lr[K0] - Lr[J] * row_bcast<K0>(Lr[J]);
+      Lr[K0] = li >= K0 ? upd : Lr[K0];
+      chold_update<J, K0 + 1>(Lr, li);
+    }
+  }
+  // forward substitution, rows I .. NV - 1:  w[I] = (w[I] - sum_{t < I} L[I][t] w[t]) / L[I][I]
+  template <int I, int T>
+  PF_DEV void chold_fwd_row(const float (&Lr)[NLT], const float (&w)[NV], float& sacc) {
+    if constexpr (CHOLD && T < I) { sacc -= row_bcast<I>(Lr[T]) * w[T]; chold_fwd_row<I, T + 1>(Lr, w, sacc); }
+  }
+  template <int I>
+  PF_DEV void chold_fwd(const float (&Lr)[NLT], float mydi, float (&w)[NV]) {
+    if constexpr (CHOLD && I < NV) {
+      float sacc = w[I];
+      chold_fwd_row<I, 0>(Lr, w, sacc);
+      w[I] = sacc * row_bcast<I>(mydi);
+      chold_fwd<I + 1>(Lr, mydi, w);
+    }
+  }
+  // back substitution, rows I .. 0:  w[I] = (w[I] - sum_{t > I} L[t][I] w[t]) / L[I][I]
+  template <int I, int T>
+  PF_DEV void chold_bwd_row(const float (&Lr)[NLT], const float (&w)[NV], float& sacc) {
+    if constexpr (CHOLD && T < NV) { sacc -= row_bcast<T>(Lr[I]) * w[T]; chold_bwd_row<I, T + 1>(Lr, w, sacc); }
+  }
+  template <int I>
+  PF_DEV void chold_bwd(const float (&Lr)[NLT], float mydi, float (&w)[NV]) {
+    if constexpr (CHOLD && I >= 0) {
+      float sacc = w[I];
+      chold_bwd_row<I, I + 1>(Lr, w, sacc);
+      w[I] = sacc * row_bcast<I>(mydi);
+      chold_bwd<I - 1>(Lr, mydi, w);
+    }
+  }
+#endif
   // W[row] <- M^-1 J[row]^T by forward/back substitution on the in-place Cholesky factor; Ainv = 1/(J.W)
-  PF_DEV void solve_one(Shared& sh, int rr, const float (&Lr)[NLT], const float (&dv)[NDV]) {
+  // (CHOLD: called by EVERY lane -- `store` says whether this lane's row is real)
+  PF_DEV void solve_one(Shared& sh, int rr, const float (&Lr)[NLT], const float (&dv)[NDV], bool store = true) {
     float w[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) w[i] = sh.W[rr][i];
+    if constexpr (CHOLD) {
+#if !defined(PF_HOST_EMU)
+      chold_fwd<0>(Lr, dv[0], w);
+      chold_bwd<NV - 1>(Lr, dv[0], w);
+#endif
+    } else {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      float s = w[i];
+      for (int i = 0; i < NV; ++i) {
+        float s = w[i];
 #pragma unroll
-      for (int t = 0; t < i; ++t) s -= (CHOLR ? Lr[CHOLR ? lt(i, t) : 0] : sh.M[i][t]) * w[t];
-      w[i] = s * (CHOLR ? dv[CHOLR ? i : 0] : sh.dinv[i]);
+        for (int t = 0; t < i; ++t) s -= (CHOLR ? Lr[CHOLR ? lt(i, t) : 0] : sh.M[i][t]) * w[t];
+        w[i] = s * (CHOLR ? dv[CHOLR ? i : 0] : sh.dinv[i]);
+      }
+#pragma unroll
+      for (int i = NV - 1; i >= 0; --i) {
+        float s = w[i];
+#pragma unroll
+        for (int t = i + 1; t < NV; ++t) s -= (CHOLR ? Lr[CHOLR ? lt(t, i) : 0] : sh.M[t][i]) * w[t];
+        w[i] = s * (CHOLR ? dv[CHOLR ? i : 0] : sh.dinv[i]);
+      }
     }
-#pragma unroll
-    for (int i = NV - 1; i >= 0; --i) {
-      float s = w[i];
-#pragma unroll
-      for (int t = i + 1; t < NV; ++t) s -= (CHOLR ? Lr[CHOLR ? lt(t, i) : 0] : sh.M[t][i]) * w[t];
-      w[i] = s * (CHOLR ? dv[CHOLR ? i : 0] : sh.dinv[i]);
-    }
+    if (!store) return;
     float a = 0.0f;
 #pragma unroll
     for (int t = 0; t < NV; ++t) { a += sh.J[rr][t] * w[t]; sh.W[rr][t] = w[t]; }
     sh.rAinv[rr] = pf_rcp(fmaxf(a, 1e-9f));
   }
   PF_DEV void solve_rows(Shared& sh, int nrows, bool with_free, const float (&Lr)[NLT], const float (&dv)[NDV]) {
-    PF_LANES(x, nrows + (with_free ? 1 : 0)) { solve_one(sh, x < nrows ? x : RFREE, Lr, dv); }
+    if constexpr (CHOLD) {      // at most PF_W rows (3 MAXC + 1 <= 32): one pass, every lane active
+      const int x = PF_LANE_ID, n = nrows + (with_free ? 1 : 0);
+      solve_one(sh, x < nrows ? x : RFREE, Lr, dv, x < n);
+    } else {
+      PF_LANES(x, nrows + (with_free ? 1 : 0)) { solve_one(sh, x < nrows ? x : RFREE, Lr, dv); }
+    }
   }
   PF_DEV void solve_rows_range(Shared& sh, int first, int n, const float (&Lr)[NLT], const float (&dv)[NDV]) {
-    PF_LANES(x, n) { solve_one(sh, first + x, Lr, dv); }
+    if constexpr (CHOLD) {
+      const int x = PF_LANE_ID;
+      solve_one(sh, first + (x < n ? x : 0), Lr, dv, x < n);
+    } else {
+      PF_LANES(x, n) { solve_one(sh, first + x, Lr, dv); }
+    }
   }
 
   // ------------------------------------------------------------------ observations (:320-382, :189-192)
-  PF_DEV void observations(Shared& sh, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
+  // noise_ready (DUAL): the partner wavefront has drawn the uniforms of slots [r_obs, r_obs + noise_count()) already
+  PF_DEV int noise_count(const PfConfig& c, const PfBuffers& B) {
+    return c.num_obs + ((B.d_priv && c.measure_heights && c.num_priv_obs > c.num_obs) ? c.num_height_points : 0);
+  }
+  PF_DEV void observations(Shared& sh, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step, bool noise_ready = false) {
 #if !defined(PF_HOST_EMU)
 #pragma clang fp contract(off)
 #endif
@@ -1330,6 +1537,7 @@ struct PfKernel {
     // is concatenated in front of the privileged extras), so the copy below covers it; critic-only heights (num_priv_obs >
     // num_obs) are the separate block with noise of their own.
     const int nprop = 6 + 2 * ND + na + 3;
+    if constexpr (DUAL) { if (c.add_noise && !noise_ready) noise_prepare(sh, c, inj, env, step, L.r_obs, noise_count(c, B)); }
     PF_LANES(i, no) {
       float v;
       if (i < 3) v = S[LC::base_ang_vel + i] * c.obs_scale_ang_vel;
@@ -1339,16 +1547,16 @@ struct PfKernel {
       else if (i < 6 + 2 * ND + na) v = S[LC::actions + i - 6 - 2 * ND];
       else if (i < nprop) { int k = i - 6 - 2 * ND - na; v = S[LC::commands + k] * c.commands_scale[k]; }
       else v = pf_clip((S[LC::root + 2] - 0.5f) - hts[i - nprop], -1.0f, 1.0f) * c.obs_scale_height;
-      if (c.add_noise) v += (2.0f * rnd(c, L, inj, env, step, L.r_obs + i) - 1.0f) * c.obs_noise_vec[i];
+      if (c.add_noise) v += (2.0f * (DUAL ? noise_at(sh, L, inj, env, L.r_obs, L.r_obs + i) : rnd(c, L, inj, env, step, L.r_obs + i)) - 1.0f) * c.obs_noise_vec[i];
       v = pf_clip(v, -c.clip_obs, c.clip_obs);
       B.d_obs[(size_t)env * no + i] = v;
       if (B.d_priv) B.d_priv[(size_t)env * np_ + i] = v;
     }
     if (B.d_priv && c.measure_heights && np_ > no) {
-      if (c.add_noise) noise_prepare(sh, c, inj, env, step, L.r_priv, c.num_height_points);
+      if (c.add_noise && !DUAL) noise_prepare(sh, c, inj, env, step, L.r_priv, c.num_height_points);
       PF_LANES(j, c.num_height_points) {    // :367-373
         float h = pf_clip((S[LC::root + 2] - 0.5f) - hts[j], -1.0f, 1.0f) * c.obs_scale_height;
-        if (c.add_noise) h += (2.0f * noise_at(sh, L, inj, env, L.r_priv, L.r_priv + j) - 1.0f) * c.priv_height_noise;
+        if (c.add_noise) h += (2.0f * noise_at(sh, L, inj, env, DUAL ? L.r_obs : L.r_priv, L.r_priv + j) - 1.0f) * c.priv_height_noise;
         B.d_priv[(size_t)env * np_ + no + j] = pf_clip(h, -c.clip_obs, c.clip_obs);
       }
     }
@@ -1426,9 +1634,12 @@ struct PfKernel {
   // ------------------------------------------------------------------ the whole step for env `env`
   // Every wavefront stages the workgroup's read-only block itself (same values from every wave: no cross-wave ordering is
   // needed, so PF_SYNC stays wave-local and robots of one workgroup may diverge freely).
-  PF_DEV void run(Shared& sh, SharedRO& ro, const PfStepArgs& g, int env) {
+  // role (DUAL instances): 0 = the wavefront that runs the step (alone: every other instance), 1 = its partner, which runs the
+  // contact side of every substep and nothing else
+  PF_DEV void run(Shared& sh, SharedRO& ro, const PfStepArgs& g, int env, int role = 0) {
     const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
     ModelS& ms = ro.mdl;
+    if constexpr (DUAL) { if (role == 1 && (g.mode != 0 || inj.d_root)) return; }      // no substeps: nothing for the partner to do
     if (g.mode == 1 && g.reset_mask && !g.reset_mask[env]) return;      // reset_idx(env_ids): this env is not in the subset
 #if defined(PF_STAMPS) && !defined(PF_HOST_EMU)
     if (threadIdx.x == 0) { sh.stamp_last = __builtin_amdgcn_s_memtime(); for (int t = 0; t < PF_NSTAMP; ++t) sh.stamp_acc[t] = 0; }
@@ -1442,6 +1653,36 @@ struct PfKernel {
     const ModelS& m = ms;
     float* S = sh.rec;
     float* grow = B.d_state + (size_t)env * L.rec_floats;
+    if constexpr (DUAL) {
+      if (role == 1) {      // the contact wavefront: per substep, between the two meetings with its partner
+        PF_SYNC();          // (its own copy of the model image is in place)
+        for (int sub = 0; sub < c.decimation; ++sub) {
+          PF_XSYNC();       // the record holds this substep's state (and, the first time, the step's anchor cell)
+          const int ix0 = sh.anchor_x[0], iy0 = sh.anchor_x[1];
+          kinematics<false, true>(sh, m, c, L);
+          // the bodies' spatial inertias and their composites depend on positions only, and this wavefront has time to spare:
+          // it builds them on its own frames and flags them (the dynamics side picks them up after its velocity pass)
+          if constexpr (PF_DUAL_INERTIA != 0) {
+            PF_LANES(i, NBD) { float I10[10]; body_inertia<true>(sh, m, i, I10); }
+            PF_SYNC();
+            composite_inertias(sh, m);
+            PF_HANDOFF_SET(sh.flag_x, sub + 1);
+          }
+          const int nc = substep_contacts<true>(sh, m, c, L, B, env, sub, ix0, iy0);
+          PF_ONE { sh.ncon_x = nc; }
+          PF_XSYNC();       // rows, targets and the contact count are handed over
+        }
+        // while the partner solves and integrates the last substep: the step's observation noise (state-independent), into the
+        // contact scratch, which is dead from here on
+        if (c.add_noise) noise_prepare(sh, c, inj, env, g.step_counter, L.r_obs, noise_count(c, B));
+        PF_XSYNC();         // the record holds the final state (world coordinates)
+        float hs_ = 0.0f;
+        if (c.measure_heights) hs_ = height_scan(sh, c, B, env);
+        PF_ONE { sh.hsum_x = hs_; }
+        PF_XSYNC();         // heights, their sum and the noise draws are handed over (post_physics)
+        return;
+      }
+    }
     PF_LANES(i, L.rec_floats) S[i] = grow[i];
     PF_SYNC();
     if (g.mode == 1) {
@@ -1484,24 +1725,34 @@ struct PfKernel {
         lx0 = (cx - bx) * c.hscale; ly0 = (cy - by) * c.hscale;
       }
       PF_SYNC();
-      PF_ONE { S[LC::root] = lx0; S[LC::root + 1] = ly0; }
+      PF_ONE { S[LC::root] = lx0; S[LC::root + 1] = ly0; if constexpr (DUAL) { sh.anchor_x[0] = ix0; sh.anchor_x[1] = iy0; sh.flag_x = 0; sh.park_x[0] = gx; sh.park_x[1] = gy; sh.park_x[2] = lx0; sh.park_x[3] = ly0; } }      // (flag: no substep's token)
       PF_SYNC();
       for (int sub = 0; sub < c.decimation; ++sub) {     // :180-185
         PF_STAMP(sh, 0);
+        if constexpr (DUAL) PF_XSYNC();      // the partner starts this substep's contact side
         bool pd = true;
         if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { actuator_torques(sh, ro.act, c); pd = false; } }
         if (pd) torques(sh, c, L, S + LC::dof_pos, 1, LC::dof_vel - LC::dof_pos);
         PF_STAMP(sh, 12);
         bool ext = sub == 0 && S[LC::ext_force + 3] != 0.0f;
-        substep(sh, m, c, L, B, ext, env, sub, ix0, iy0);
+        if constexpr (DUAL) {
+          float Lr[NLT], dv[NDV];
+          substep_dyn(sh, m, c, L, B, ext, env, Lr, dv, sub + 1);
+          PF_XSYNC();                        // ... and has finished it
+          PF_STAMP(sh, 5);
+          substep_solve(sh, m, c, L, B, env, sub, sh.ncon_x, Lr, dv);
+        } else substep(sh, m, c, L, B, ext, env, sub, ix0, iy0);
         if (ext) { PF_ONE { S[LC::ext_force + 3] = 0.0f; } PF_SYNC(); }
       }
       {
-        const float nx = gx + (S[LC::root] - lx0), ny = gy + (S[LC::root + 1] - ly0);
+        float gx_ = gx, gy_ = gy, lx_ = lx0, ly_ = ly0;
+        if constexpr (DUAL) { gx_ = sh.park_x[0]; gy_ = sh.park_x[1]; lx_ = sh.park_x[2]; ly_ = sh.park_x[3]; }
+        const float nx = gx_ + (S[LC::root] - lx_), ny = gy_ + (S[LC::root + 1] - ly_);
         PF_SYNC();
         PF_ONE { S[LC::root] = nx; S[LC::root + 1] = ny; }
         PF_SYNC();
       }
+      if constexpr (DUAL) PF_XSYNC();      // the partner starts the height scan on the final state
       kinematics<false>(sh, m, c, L);
       PF_LANES(e, NF * 3) {      // origin of the foot's link frame: on its carrier body at feet_off
         // (same operations, same order as the kinematics chain would use for a body of its own: r_foot = r_carrier + R_carrier off)
@@ -1512,7 +1763,7 @@ struct PfKernel {
       PF_SYNC();
     }
     PF_STAMP(sh, 13);
-    post_physics(sh, m, c, L, B, inj, env, g.step_counter);
+    post_physics(sh, m, c, L, B, inj, env, g.step_counter, DUAL && !inj.d_root);
     PF_STAMP(sh, 14);
     PF_LANES(i, L.rec_floats) grow[i] = S[i];
     PF_SYNC();
@@ -1590,7 +1841,8 @@ struct PfKernel {
   }
 
   // ------------------------------------------------------------------ post_physics_step (:195-230)
-  PF_DEV void post_physics(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step) {
+  // partner (DUAL): the partner wavefront draws the observation noise and runs the height scan meanwhile; it is met before the rewards
+  PF_DEV void post_physics(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, const PfInject& inj, int env, long long step, bool partner = false) {
 #if !defined(PF_HOST_EMU)
 #pragma clang fp contract(off)
 #endif
@@ -1611,7 +1863,7 @@ struct PfKernel {
     // :212-213, :1048-1075 height scan -- one point per lane
     float root_z = S[LC::root + 2];
     float hsum = 0.0f;
-    if (c.measure_heights) hsum = height_scan(sh, c, B, env);
+    if (c.measure_heights && !partner) hsum = height_scan(sh, c, B, env);
     // :1114-1129 feet state machine (PointFoot only; LeggedRobot keeps it inside _reward_feet_air_time)
     if constexpr (!LR) PF_LANES(f, NF) {
       bool first = S[LC::first_contact + f] != 0.0f, filt = S[LC::contact_filt + f] != 0.0f;
@@ -1671,6 +1923,7 @@ struct PfKernel {
     }
     bool time_out = (float)ep > c.max_episode_length;
     bool reset = term || time_out;
+    if constexpr (DUAL) { if (partner) { PF_XSYNC(); hsum = sh.hsum_x; } }      // height scan and noise draws are in place
     // :301-318 rewards: one lane per reward term (the terms are independent; a loop over them pays a scalar load of the term's id, a
     // branch and the term's LDS reads one after the other, 19 times); the scaled terms are then added up in term order by every lane --
     // the same sum as the loop's
@@ -1767,7 +2020,7 @@ struct PfKernel {
     }
     PF_SYNC();
     if (reset) reset_env(sh, m, c, L, B, inj, env, step);      // :221-222 masked reset
-    observations(sh, c, L, B, inj, env, step);                  // :223
+    observations(sh, c, L, B, inj, env, step, partner);         // :223
     PF_SYNC();
     PF_LANES(k, c.num_actions) S[LC::last_actions + k] = S[LC::actions + k];    // :225-227
     PF_LANES(k, ND) S[LC::last_dof_vel + k] = S[LC::dof_vel + k];

@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("PF_LIB_VARIANT"):      # development: run the suite on a variant build of the library (tools/build_variant.sh)
+        from pointfoot_amd import _abi
+        _abi.lib_path = lambda: os.path.abspath(os.environ["PF_LIB_VARIANT"])
 
 
 def _emu_requested():

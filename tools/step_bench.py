@@ -3,6 +3,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from pointfoot_amd import _abi
+if os.environ.get("PF_LIB_VARIANT"):      # a variant build of the library (tools/build_variant.sh)
+    _abi.lib_path = lambda: os.path.abspath(os.environ["PF_LIB_VARIANT"])
 from pointfoot_amd.envs import task_registry
 from pointfoot_amd.utils import get_args
 
