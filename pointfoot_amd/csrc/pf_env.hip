@@ -36,7 +36,7 @@ void pf_set_error(const std::string& s) { g_pf_error = s; }
 // DUAL: a workgroup is TWO wavefronts for the same RPW robots (WPB == 1): wave 0 runs the step, wave 1 the contact side of its
 // substeps (PfKernel::run, role).
 template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0), int NBD = NB, bool DUAL = false>
-__global__ __launch_bounds__(64 * WPB * (DUAL ? 2 : 1), (WPB == 1 || DUAL) ? WAVES : 1) void pf_step_kernel(const void* __restrict__ packed, const PfConfig* __restrict__ cfg, PfStepArgs g) {
+__global__ __launch_bounds__(64 * WPB * (DUAL ? 2 : 1), (WPB == 1 || DUAL) ? WAVES : (WPB <= 4 ? 2 : 1)) void pf_step_kernel(const void* __restrict__ packed, const PfConfig* __restrict__ cfg, PfStepArgs g) {
   using K = PfKernel<NB, ND, NF, KIND, KS, RPW, KPR, NBD, DUAL>;
   static_assert(!DUAL || WPB == 1, "a DUAL workgroup is one pair of wavefronts");
   extern __shared__ __attribute__((aligned(16))) unsigned char pf_lds[];
@@ -122,6 +122,12 @@ constexpr int PF_NBD_POINTFOOT = 7, PF_NBD_QUAD = 13;
 #define PF_POINT_DUAL 1
 #endif
 using PfKernelPoint = PfKernel<9, 6, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 16, PF_NBD_POINTFOOT, PF_POINT_DUAL != 0>;
+// quadruped instances: robots (= wavefronts) per workgroup.  A workgroup's LDS is released when its LAST wavefront ends, so the
+// next workgroup of a CU waits for the slowest robot of the one before: 8 per workgroup = one workgroup per CU, 4 = two
+// (measured, anymal_c_rough, 8192 envs, same box: 8 -> 538 us, 4 -> 520 us, 2 -> 549 us: every workgroup stages the read-only block).
+#ifndef PF_QUAD_WPB
+#define PF_QUAD_WPB 4
+#endif
 using PfKernelQuad = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 0, PF_NBD_QUAD>;
 using PfKernelQuadSelf = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_KPAIR_QUAD, PF_NBD_QUAD>;
 static int pf_validate(const PfModel* m, const PfConfig* c) {
@@ -277,8 +283,8 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
     if (lds > 64 * 1024 && !raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
     hipLaunchKernelGGL(kern, dim3((N + robots_per_block - 1) / robots_per_block), dim3(threads), lds, s, e->d_packed, e->d_cfg, g);
   };
-  if (e->instance == 2) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, PF_KPAIR_QUAD, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuadSelf, 1, 8>(), 8, 512);
-  else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, 8, 0, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuad, 1, 8>(), 8, 512);
+  if (e->instance == 2) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, PF_KPAIR_QUAD, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuadSelf, 1, PF_QUAD_WPB>(), PF_QUAD_WPB, 64 * PF_QUAD_WPB);
+  else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, 0, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuad, 1, PF_QUAD_WPB>(), PF_QUAD_WPB, 64 * PF_QUAD_WPB);
   else if (PF_POINT_DUAL) launch(pf_step_kernel<9, 6, 2, 4, PF_KIND_POINTFOOT, PF_KSPH, 2, 1, 16, PF_NBD_POINTFOOT, PF_POINT_DUAL != 0>, pf_lds_bytes<PfKernelPoint, 2, 1>(), 2, 128);
   else launch(pf_step_kernel<9, 6, 2, 2, PF_KIND_POINTFOOT, PF_KSPH, 2, 1, 16, PF_NBD_POINTFOOT, false>, pf_lds_bytes<PfKernelPoint, 2, 1>(), 2, 64);
   PF_HIP_OK(hipGetLastError());

@@ -393,7 +393,14 @@ struct PfKernel {
     unsigned stamp_acc[PF_NSTAMP];
 #endif
     float rec[REC_MAX];
-    float gates[LR ? ND * 32 : 1];            // LSTM gate pre-activations
+    // LSTM gate pre-activations, gate-major: gate c of (joint j, unit u) at c * GST + 8 j + u -- the 32 rows a joint's lanes
+    // write (4 gates x 8 units) and the 4 values a (joint, unit) lane reads fall into distinct banks (GST = 8 ND + 8)
+    // (the gates live from the start of a substep to its torques, the mass matrix / its factor from the mass-matrix phase to the
+    // last solve of the same substep: one storage)
+    union {
+      float gates[LR ? 4 * (ND * 8 + 8) : 1];
+      float M[NV][NVP];
+    };
     float Rw[NBD][9], r[NBD][3], ax[NBD][3];
     // The dynamics scratch (dead once the mass matrix and the bias are built) and the contact candidates (born after the
     // factorisation, dead after the contact rows) share storage when ONE wavefront runs both (union); with a wavefront for
@@ -418,7 +425,6 @@ struct PfKernel {
     typename std::conditional<DUAL, KinB, None>::type kb;      // the contact wavefront's own body frames (same arithmetic, same bits)
     int ncon_x, anchor_x[2], flag_x; float hsum_x;             // handed from one wavefront to the other (DUAL)
     float park_x[4];                                           // values of the step parked across the substep loop (DUAL: 128 VGPRs)
-    float M[NV][NVP];
     float dinv[NV];
     float bias[NV], vel[NV], vold[NV];
     float J[NROWS][NVP], W[NROWS][NVP];
@@ -583,6 +589,20 @@ struct PfKernel {
     return 1.0f - 2.0f * pf_rcp(__expf(2.0f * xc) + 1.0f);
 #endif
   }
+  // The three 32 x 8 weight blocks are staged TRANSPOSED in LDS (stage_actuator): lane (joint, gate row g) reads element t of its
+  // row at base + 32 t + g -- the rows of a wavefront's lanes lie side by side -- instead of base + 8 g + t, where 32 rows share
+  // four banks (an 8-way conflict on every weight read: most of the quadruped kernel's 8.8 % LDS conflict cycles, round 3).
+  static constexpr int GST = ND * 8 + 8;
+  PF_DEV int act_w(int base, int g, int t) { return base + 32 * t + g; }
+  PF_DEV void stage_actuator(float* dst, const float* __restrict__ src) {
+    PF_LANES(i, PF_ACT_PARAMS) {
+      int o = i;
+      const int blk = (i >= PF_ACT_W_HH0 && i < PF_ACT_W_HH0 + 256) ? PF_ACT_W_HH0 : (i >= PF_ACT_W_IH1 && i < PF_ACT_W_IH1 + 256) ? PF_ACT_W_IH1
+                    : (i >= PF_ACT_W_HH1 && i < PF_ACT_W_HH1 + 256) ? PF_ACT_W_HH1 : -1;
+      if (blk >= 0) { const int r = i - blk; o = act_w(blk, r >> 3, r & 7); }
+      dst[o] = src[i];
+    }
+  }
   PF_DEV void actuator_torques(Shared& sh, const float* P, const PfConfig& c) {
     float* S = sh.rec;
     for (int layer = 0; layer < 2; ++layer) {
@@ -594,19 +614,19 @@ struct PfKernel {
           float x0 = ((S[LC::actions + j] * c.action_scale + c.default_dof_pos[j]) - S[LC::dof_pos + j]) * P[PF_ACT_IN_SCALE];
           float x1 = S[LC::dof_vel + j] * P[PF_ACT_IN_SCALE + 1];
           acc = P[PF_ACT_B_IH0 + g] + P[PF_ACT_B_HH0 + g] + P[PF_ACT_W_IH0 + 2 * g] * x0 + P[PF_ACT_W_IH0 + 2 * g + 1] * x1;
-          for (int t = 0; t < 8; ++t) acc += P[PF_ACT_W_HH0 + 8 * g + t] * st[t];
+          for (int t = 0; t < 8; ++t) acc += P[act_w(PF_ACT_W_HH0, g, t)] * st[t];
         } else {
           acc = P[PF_ACT_B_IH1 + g] + P[PF_ACT_B_HH1 + g];
-          for (int t = 0; t < 8; ++t) acc += P[PF_ACT_W_IH1 + 8 * g + t] * st[t] + P[PF_ACT_W_HH1 + 8 * g + t] * st[16 + t];
+          for (int t = 0; t < 8; ++t) acc += P[act_w(PF_ACT_W_IH1, g, t)] * st[t] + P[act_w(PF_ACT_W_HH1, g, t)] * st[16 + t];
         }
-        sh.gates[e] = acc;
+        sh.gates[(g >> 3) * GST + 8 * j + (g & 7)] = acc;
       }
       PF_SYNC();
       PF_LANES(e, ND * 8) {
         int j = e >> 3, u = e & 7;
-        const float* G = sh.gates + j * 32;
+        const float* G = sh.gates + e;
         float* st = S + LC::lstm_state + j * 32 + layer * 16;
-        float ig = sigm(G[u]), fg = sigm(G[8 + u]), gg = tanh_(G[16 + u]), og = sigm(G[24 + u]);
+        float ig = sigm(G[0]), fg = sigm(G[GST]), gg = tanh_(G[2 * GST]), og = sigm(G[3 * GST]);
         float cn = fg * st[8 + u] + ig * gg;
         st[8 + u] = cn;
         st[u] = og * tanh_(cn);
@@ -868,21 +888,23 @@ struct PfKernel {
       float r[NV];
 #pragma unroll
       for (int t = 0; t < NV; ++t) r[t] = (li < NV && t <= li) ? sh.M[li < NV ? li : 0][t] : 0.0f;
+      // right-looking: once column j is scaled, every remaining entry (i, k), j < k <= i, takes its update -L[i][j] L[k][j] at
+      // once -- NV - 1 - j independent multiply-adds per column (L[k][j] by v_readlane: wave-uniform) instead of one dependent
+      // chain per entry; every entry still receives its updates in the order j = 0, 1, ..: the same sums, bit for bit
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        float pj[NV];
-#pragma unroll
-        for (int t = 0; t < j; ++t) pj[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[t]), j));
         float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[j]), j));
-#pragma unroll
-        for (int t = 0; t < j; ++t) d -= pj[t] * pj[t];
         d = pf_sqrt(fmaxf(d, 1e-12f));
         const float di = pf_rcp(d);
-        float sacc = r[j];
-#pragma unroll
-        for (int t = 0; t < j; ++t) sacc -= r[t] * pj[t];
-        r[j] = li > j ? sacc * di : r[j];
+        const float lij = r[j] * di;
+        r[j] = li > j ? lij : r[j];
         if (li == j) sh.dinv[j] = di;
+#pragma unroll
+        for (int k = j + 1; k < NV; ++k) {
+          const float lkj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[j]), k));
+          const float upd = r[k] - r[j] * lkj;
+          r[k] = li >= k ? upd : r[k];
+        }
       }
       if (li < NV) {
 #pragma unroll
@@ -1649,7 +1671,7 @@ struct PfKernel {
       uint32_t* dst = reinterpret_cast<uint32_t*>(&ms);
       PF_LANES(i, (int)(sizeof(ModelS) / 4)) dst[i] = src[i];
     }
-    if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { PF_LANES(i, PF_ACT_PARAMS) ro.act[i] = B.d_actuator_params[i]; } }
+    if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) stage_actuator(ro.act, B.d_actuator_params); }
     const ModelS& m = ms;
     float* S = sh.rec;
     float* grow = B.d_state + (size_t)env * L.rec_floats;
