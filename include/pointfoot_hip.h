@@ -199,9 +199,13 @@ typedef struct PfConfig {
 } PfConfig;
 
 /* Per-env state record: one contiguous row of `rec_floats` floats per env (AoS: a wavefront owns
- * one env, so its record is one coalesced burst).  Offsets come from pf_layout(). */
+ * one env, so its record is one coalesced burst).  Offsets come from pf_layout().
+ * The record is in two parts, each a whole number of 64-byte lines: [0, rw_floats) is what a step READS and writes (state that
+ * carries over), [rw_floats, rec_used) what a step only WRITES (actions as clipped, torques, base-frame velocities, projected
+ * gravity, net contact forces, feet positions: outputs the caller reads).  pf_step does not load the second part. */
 typedef struct PfLayout {
   int32_t rec_floats;
+  int32_t rw_floats, rec_used;
   int32_t root, dof_pos, dof_vel, actions, last_actions, last_dof_vel, last_root_vel, commands, torques;
   int32_t base_lin_vel, base_ang_vel, projected_gravity;
   int32_t feet_air_time, last_feet_air_time, cur_max_feet_height, last_max_feet_height, feet_height;
@@ -405,6 +409,10 @@ int32_t ppo_grad_groups(const PpoConfig* cfg, int64_t* ranges4);
 int32_t ppo_supports_parts(const PpoAlg* alg);
 /* grad-norm clip (over the possibly all-reduced d_grads, divided by world_size) + Adam step */
 int ppo_minibatch_apply(PpoAlg* alg, void* stream);
+/* ppo_minibatch_backward + ppo_minibatch_apply for ONE process (world_size == 1: nothing happens to d_grads between the two): the
+ * slab reduction leaves the gradient norm's first stage, and clip coefficient, adaptive learning rate and Adam run as one launch
+ * (two launches fewer per minibatch).  Same arithmetic except the summation order of the squared norm. */
+int ppo_minibatch_step(PpoAlg* alg, int32_t minibatch_index, void* stream);
 
 #ifdef __cplusplus
 }

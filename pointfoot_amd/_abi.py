@@ -93,7 +93,7 @@ class PfConfig(C.Structure):
 
 class PfLayout(C.Structure):
     _fields_ = [(n, i32) for n in (
-        "rec_floats", "root", "dof_pos", "dof_vel", "actions", "last_actions", "last_dof_vel", "last_root_vel",
+        "rec_floats", "rw_floats", "rec_used", "root", "dof_pos", "dof_vel", "actions", "last_actions", "last_dof_vel", "last_root_vel",
         "commands", "torques", "base_lin_vel", "base_ang_vel", "projected_gravity",
         "feet_air_time", "last_feet_air_time", "cur_max_feet_height", "last_max_feet_height", "feet_height",
         "contact_filt", "first_contact", "last_contacts", "contact_forces", "feet_pos", "ext_force", "env_origin",
@@ -206,6 +206,7 @@ def _bind_ppo(lib):
     lib.ppo_minibatch_backward.argtypes = [vp, i32, vp]
     lib.ppo_begin_update.argtypes = [vp, vp]
     lib.ppo_minibatch_apply.argtypes = [vp, vp]
+    lib.ppo_minibatch_step.argtypes = [vp, i32, vp]
     lib.ppo_minibatch_backward_part.argtypes = [vp, i32, i32, vp]
     lib.ppo_minibatch_backward_part.restype = i32
     lib.ppo_grad_groups.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -213,7 +214,7 @@ def _bind_ppo(lib):
     lib.ppo_supports_parts.argtypes = [vp]
     lib.ppo_supports_parts.restype = i32
     for fn in ("ppo_bind_buffers", "ppo_act", "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns",
-               "ppo_normalize_advantages", "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_apply"):
+               "ppo_normalize_advantages", "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_apply", "ppo_minibatch_step"):
         getattr(lib, fn).restype = i32
 
 
@@ -228,4 +229,4 @@ EXPORTED_SYMBOLS = [
     "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations",
     "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act",
     "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",
-    "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_backward_part", "ppo_grad_groups", "ppo_supports_parts", "ppo_minibatch_apply"]
+    "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_backward_part", "ppo_grad_groups", "ppo_supports_parts", "ppo_minibatch_apply", "ppo_minibatch_step"]

@@ -38,6 +38,10 @@ struct GemmArgs {
   const unsigned short* Bp;
   int ldbp;
   long long bplane;
+  // diagnostic builds of pf_gemm3f.h only (-DG3F_EMIT_PLANES, tools/gemm_dma_ablate.hip): the write-out ALSO stores the result as
+  // three bf16 planes [3][M][ldc] -- what a weight-gradient GEMM fed by LDS-DMA would consume; the product never sets it
+  unsigned short* Cp;
+  long long cplane;
 };
 
 __device__ __forceinline__ float pf_elu(float x) { return x > 0.0f ? x : (__expf(x) - 1.0f); }

@@ -41,6 +41,11 @@ __device__ __forceinline__ void g3f_dma16(const g3f_u4& rsrc, unsigned voff, uns
 #ifndef G3F_ABLATE
 #define G3F_ABLATE 0
 #endif
+// Diagnostic builds only: 1 = the write-out also emits the result as three bf16 planes (GemmArgs::Cp) -- the producer side of
+// "activations as planes for the weight gradients", measured in profiles/r4_plane_copy_ablation.txt.  The library builds with 0.
+#ifndef G3F_EMIT_PLANES
+#define G3F_EMIT_PLANES 0
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define G3F_OPAQUE(...) asm volatile("" : __VA_ARGS__)      // register constraints of the ablation sinks only parse for the device
 #else
@@ -238,6 +243,14 @@ __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid,
           }
           if constexpr ((G3F_ABLATE & 64) != 0) { G3_KEEP(v.x); G3_KEEP(v.y); G3_KEEP(v.z); G3_KEEP(v.w); continue; }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g3f_u4, v), c_rs, (int)((row < g.M && col < g.N) ? ((unsigned)row * (unsigned)g.ldc + (unsigned)col) * 4u : OOB), 0, 0);
+          if constexpr (G3F_EMIT_PLANES != 0) {
+            if (g.Cp && row < g.M && col < g.N) {      // exact three-way split of the four values, one 8-byte store per plane
+              uint2 q0, q1, q2;
+              g3_split4(v, q0, q1, q2);
+              unsigned short* d = g.Cp + (size_t)row * g.ldc + col;
+              *reinterpret_cast<uint2*>(d) = q0; *reinterpret_cast<uint2*>(d + g.cplane) = q1; *reinterpret_cast<uint2*>(d + 2 * g.cplane) = q2;
+            }
+          }
         }
       }
     }

@@ -43,6 +43,7 @@ struct Net {
 };
 
 constexpr int RED_BLOCKS = 240;     // stage-1 blocks of every two-stage reduction
+constexpr int PPO_SQ_PARTIALS = 8192;   // capacity of the gradient norm's per-block partials (ppo_minibatch_step)
 
 // ------------------------------------------------------------------------------------- philox / normal
 __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* o) {
@@ -298,7 +299,8 @@ __global__ void k_normalize(size_t n, float* __restrict__ x, float* __restrict__
 // out[i] = sum_s slabs[s][i].  Block = 64 consecutive outputs x 4 slab lanes (each lane sums every 4th slab with two
 // independent accumulators), combined through LDS in a fixed order: deterministic, 4x the parallelism of one thread
 // per output and short dependent-load chains.
-__device__ __forceinline__ void reduce_body(int n, int S, const float* __restrict__ slabs, float* __restrict__ out, int bid) {
+// (every body returns the square of what this thread wrote -- the gradient norm's first stage, ppo_minibatch_step)
+__device__ __forceinline__ float reduce_body(int n, int S, const float* __restrict__ slabs, float* __restrict__ out, int bid) {
   __shared__ float sm[4][64];
   int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
   int i = bid * 64 + col;
@@ -316,10 +318,12 @@ __device__ __forceinline__ void reduce_body(int n, int S, const float* __restric
   }
   sm[sl][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
-  if (sl == 0 && i < n) out[i] = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
+  float q = 0.0f;
+  if (sl == 0 && i < n) { const float r = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]); out[i] = r; q = r * r; }
+  return q;
 }
 // same reduction, four columns per thread (n % 4 == 0, 16-byte aligned slabs and output): dwordx4 loads
-__device__ __forceinline__ void reduce4_body(int n4, int S, const float4* __restrict__ slabs, float4* __restrict__ out, int bid) {
+__device__ __forceinline__ float reduce4_body(int n4, int S, const float4* __restrict__ slabs, float4* __restrict__ out, int bid) {
   __shared__ float4 sm[4][64];
   int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
   int i = bid * 64 + col;
@@ -338,13 +342,16 @@ __device__ __forceinline__ void reduce4_body(int n4, int S, const float4* __rest
   add(a[0], a[1]); add(a[2], a[3]); add(a[0], a[2]);
   sm[sl][col] = a[0];
   __syncthreads();
+  float qq = 0.0f;
   if (sl == 0 && i < n4) {
     float4 r = sm[0][col]; add(r, sm[1][col]); float4 q = sm[2][col]; add(q, sm[3][col]); add(r, q);
     out[i] = r;
+    qq = (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
   }
+  return qq;
 }
 // few columns, many slabs (the thin heads: n ~ 800, S ~ 800): 16 columns x 16 slab lanes per block
-__device__ __forceinline__ void reduce_tall_body(int n, int S, const float* __restrict__ slabs, float* __restrict__ out, int bid) {
+__device__ __forceinline__ float reduce_tall_body(int n, int S, const float* __restrict__ slabs, float* __restrict__ out, int bid) {
   __shared__ float sm[16][17];
   int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
   int i = bid * 16 + col;
@@ -361,20 +368,23 @@ __device__ __forceinline__ void reduce_tall_body(int n, int S, const float* __re
   }
   sm[sl][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
+  float q = 0.0f;
   if (sl == 0 && i < n) {
     float t = 0.0f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) t += sm[j][col];
     out[i] = t;
+    q = t * t;
   }
+  return q;
 }
 // one split-K slab reduction: out[i] = sum_s slabs[s][i], fixed order.  kind 0: 64 columns per block; 1: 256 columns per
 // block as float4; 2: 16 columns x 16 slab lanes (few columns, many slabs)
 struct ReduceJob { int n, S, kind, blocks; const float* slabs; float* out; };
-__device__ __forceinline__ void reduce_job(const ReduceJob& j, int bid) {
-  if (j.kind == 1) reduce4_body(j.n / 4, j.S, (const float4*)j.slabs, (float4*)j.out, bid);
-  else if (j.kind == 2) reduce_tall_body(j.n, j.S, j.slabs, j.out, bid);
-  else reduce_body(j.n, j.S, j.slabs, j.out, bid);
+__device__ __forceinline__ float reduce_job(const ReduceJob& j, int bid) {
+  if (j.kind == 1) return reduce4_body(j.n / 4, j.S, (const float4*)j.slabs, (float4*)j.out, bid);
+  if (j.kind == 2) return reduce_tall_body(j.n, j.S, j.slabs, j.out, bid);
+  return reduce_body(j.n, j.S, j.slabs, j.out, bid);
 }
 __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceJob j) { reduce_job(j, (int)blockIdx.x); }
 // two reductions in one launch (the actor's and the critic's layer i)
@@ -395,20 +405,32 @@ static inline void reduce_slabs(int n, int S, const float* slabs, float* out, hi
 // reductions (dL/dstd, KL sum) when `lf.partial` is set -- the arithmetic of k_loss_finish without a launch of its own
 // (6.2 us saved for 2.5 us more in this kernel)
 struct LossFinish { int nb, A, B; float ecoef; const float* partial; const float* stdp; float* dstd; float* grads_tail; float* scalars; };
-__device__ void loss_finish_body(const LossFinish& f);
-struct ReduceJobs { ReduceJob j[2 * (PPO_MAX_LAYERS + 1)]; int n; LossFinish lf; };
+__device__ float loss_finish_body(const LossFinish& f);
+// sq_partial (ppo_minibatch_step, one process): every block leaves the sum of the squares of the gradient entries it wrote --
+// together the blocks write every entry exactly once -- so the gradient norm needs no pass of its own over the gradients
+struct ReduceJobs { ReduceJob j[2 * (PPO_MAX_LAYERS + 1)]; int n; LossFinish lf; float* sq_partial; };
 __global__ __launch_bounds__(256) void k_reduce_slabs_n(ReduceJobs js) {
+  __shared__ float smq[8];
   int b = (int)blockIdx.x;
-  for (int i = 0; i < js.n; ++i) {
-    if (b < js.j[i].blocks) { reduce_job(js.j[i], b); return; }
-    b -= js.j[i].blocks;
+  float q = 0.0f;
+  bool done = false;
+  for (int i = 0; i < js.n && !done; ++i) {
+    if (b < js.j[i].blocks) { q = reduce_job(js.j[i], b); done = true; }
+    else b -= js.j[i].blocks;
   }
-  if (js.lf.partial) loss_finish_body(js.lf);
+  if (!done && js.lf.partial) q = loss_finish_body(js.lf);
+  if (js.sq_partial) {
+    q = block_sum(q, smq);
+    if (threadIdx.x == 0) js.sq_partial[blockIdx.x] = q;
+  }
 }
-static inline void reduce_slabs_n(const ReduceJobs& js, hipStream_t s) {
+static inline int reduce_slabs_n_blocks(const ReduceJobs& js) {
   int blocks = js.lf.partial ? 1 : 0;
   for (int i = 0; i < js.n; ++i) blocks += js.j[i].blocks;
-  hipLaunchKernelGGL(k_reduce_slabs_n, dim3(blocks), dim3(256), 0, s, js);
+  return blocks;
+}
+static inline void reduce_slabs_n(const ReduceJobs& js, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_slabs_n, dim3(reduce_slabs_n_blocks(js)), dim3(256), 0, s, js);
 }
 static inline void reduce_slabs2(const ReduceJob& j0, const ReduceJob& j1, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_slabs2, dim3(j0.blocks + j1.blocks), dim3(256), 0, s, j0, j1);
@@ -792,7 +814,7 @@ __global__ __launch_bounds__(256) void k_heads(int B, int A, int Ka, int Kc, flo
   }
 }
 // finish the loss reductions: dL/dstd (incl. the entropy bonus), KL sum + count for the adaptive LR
-__device__ void loss_finish_body(const LossFinish& f) {
+__device__ float loss_finish_body(const LossFinish& f) {      // returns the square of the std gradient entry this thread wrote (else 0)
   const int nb = f.nb, A = f.A, B = f.B;
   const float ecoef = f.ecoef;
   const float* __restrict__ partial = f.partial; const float* __restrict__ stdp = f.stdp;
@@ -815,17 +837,19 @@ __device__ void loss_finish_body(const LossFinish& f) {
   }
   sm[r][c] = s;
   __syncthreads();
+  float wrote = 0.0f;
   if (r == 0 && c < A + 4) {
     float t = 0.0f;
     for (int i = 0; i < 8; ++i) t += sm[i][c];
-    if (c < A) dstd[c] = t - ecoef / stdp[c];
+    if (c < A) { const float g = t - ecoef / stdp[c]; dstd[c] = g; wrote = g * g; }
     else if (c == A) { grads_tail[0] = t; grads_tail[1] = (float)B; }
     else if (c == A + 1) scalars[SC_VLOSS] += t / (float)B;
     else if (c == A + 2) scalars[SC_SLOSS] += t / (float)B;
     else scalars[SC_ENTROPY] = t / (float)B;
   }
+  return wrote;
 }
-__global__ __launch_bounds__(256) void k_loss_finish(LossFinish f) { loss_finish_body(f); }
+__global__ __launch_bounds__(256) void k_loss_finish(LossFinish f) { (void)loss_finish_body(f); }
 
 // ------------------------------------------------------------------------------------- optimiser
 __global__ void k_sumsq1(size_t n, const float* __restrict__ g, float scale, float* __restrict__ partial) {
@@ -872,6 +896,50 @@ __global__ void k_adam(size_t n, float* __restrict__ p, const float* __restrict_
   }
 }
 
+// One process (no gradient all-reduce between the backward pass and the optimiser): grad-norm clip, adaptive-KL learning rate and
+// Adam in ONE launch.  Every block adds up the norm's first stage (k_reduce_slabs_n's per-block squares, fixed order: every block
+// gets the same bits), takes the learning-rate decision for itself from the scalars of the PREVIOUS step, and steps its share of
+// the parameters; the block that finishes last (ticket) publishes the new scalars -- by then every block has read the old ones.
+__global__ __launch_bounds__(256) void k_adam_fused(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    int nsq, const float* __restrict__ sq_partial, const float* __restrict__ grads_tail, int adaptive,
+                                                    float desired_kl, float max_grad_norm, float b1, float b2, float eps, float* __restrict__ scalars,
+                                                    unsigned* __restrict__ ticket) {
+  __shared__ float sm[8];
+  __shared__ bool last;
+  float q = 0.0f;
+  for (int b = threadIdx.x; b < nsq; b += blockDim.x) q += sq_partial[b];
+  q = block_sum(q, sm);
+  const float norm = sqrtf(q);
+  float coef = max_grad_norm / (norm + 1e-6f);
+  coef = coef < 1.0f ? coef : 1.0f;
+  const float kl = grads_tail[0] / grads_tail[1];
+  float lr = scalars[SC_LR];
+  if (adaptive && desired_kl > 0.0f) {
+    if (kl > desired_kl * 2.0f) lr = fmaxf(1e-5f, lr / 1.5f);
+    else if (kl < desired_kl / 2.0f && kl > 0.0f) lr = fminf(1e-2f, lr * 1.5f);
+  }
+  const float t = scalars[SC_STEP] + 1.0f, nupd = scalars[SC_NUPD] + 1.0f;
+  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  const float step = lr / bc1, ibc2s = 1.0f / sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step * mi / (sqrtf(vi) * ibc2s + eps);
+  }
+  __syncthreads();      // every thread of this block has read the old scalars (and is done with them)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    scalars[SC_GNORM] = norm; scalars[SC_CLIPCOEF] = coef; scalars[SC_KL] = kl; scalars[SC_LR] = lr; scalars[SC_STEP] = t; scalars[SC_NUPD] = nupd;
+    *ticket = 0u;
+  }
+}
+
 }  // namespace
 
 // ============================================================================================ host side
@@ -891,7 +959,9 @@ struct PpoAlg {
   bool permuted = false;   // w_perm holds the current permutation (set by ppo_begin_update, dropped by the next rollout)
   size_t w_ha[PPO_MAX_LAYERS], w_hc[PPO_MAX_LAYERS];   // activations per layer output (last = head output)
   size_t w_wp[2][PPO_MAX_LAYERS], w_wtp[2][PPO_MAX_LAYERS];      // bf16 planes of W (and W^T) per hidden layer, in floats of workspace
-  size_t w_dmean, w_dvalue, w_g[2][PPO_MAX_LAYERS], w_slabs[2], w_slabl[2][PPO_MAX_LAYERS + 1], w_partial, w_lastval, w_total;   // [0] actor / [1] critic scratch (run concurrently)
+  size_t w_dmean, w_dvalue, w_g[2][PPO_MAX_LAYERS], w_slabs[2], w_slabl[2][PPO_MAX_LAYERS + 1], w_partial, w_sqpart, w_lastval, w_total;
+  int sq_blocks = 0;       // blocks of the last whole-pass slab reduction that left gradient-norm partials (0: none)
+  bool ticket_zeroed = false;   // [0] actor / [1] critic scratch (run concurrently)
   hipStream_t aux = nullptr;        // second stream: the critic network runs beside the actor network
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool dual = true, fused_heads = true;
@@ -1000,6 +1070,7 @@ static void ppo_plan(PpoAlg* a) {
     }
   }
   a->w_partial = take(std::max<size_t>((size_t)RED_BLOCKS * 24, thin_blocks * 20));
+  a->w_sqpart = take(PPO_SQ_PARTIALS + 4);      // per-block squares of the slab-reduction launch (+ the fused optimiser's ticket word)
   a->w_lastval = take(c.num_envs);
   a->w_total = w;
 }
@@ -1168,7 +1239,7 @@ static void mlp_forward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M,
 //           [actor / critic layers >= 1, std, KL tail]; the loss scalars are finished here;
 //   part 1: data gradient into layer 0's output, the input layers' weight gradients -> LATE group [actor L0, critic L0].
 // The flat parameter / gradient buffer is laid out group by group (ppo_plan), so each group is ONE contiguous range.
-static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s, int ldxa = 0, int ldxc = 0, const LossFinish* lf = nullptr, int part = -1) {
+static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M, hipStream_t s, int ldxa = 0, int ldxc = 0, const LossFinish* lf = nullptr, int part = -1, bool want_sq = false) {
   const int ldx[2] = {ldxa, ldxc};
   float* ws = a->b.d_workspace; const float* P = a->b.d_params; float* G = a->b.d_grads;
   const Net* net[2] = {&a->actor, &a->critic};
@@ -1176,7 +1247,7 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
   const float* X[2] = {Xa, Xc};
   const int last = a->actor.nl - 1;
   auto g_of = [&](int set, int i) { return ws + a->w_g[set][i]; };
-  ReduceJobs js; js.n = 0; js.lf = LossFinish{};
+  ReduceJobs js; js.n = 0; js.lf = LossFinish{}; js.sq_partial = nullptr;
   auto bwd_x = [&](int i) {      // dZ_{i-1} = (g_i W_i) * ELU'(h_{i-1})
     GemmArgs g[2];
     for (int k = 0; k < 2; ++k) {
@@ -1239,6 +1310,8 @@ static void mlp_backward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M
   if (part < 0) {
     head_jobs();
     for (int i = last - 1; i >= 0; --i) { if (i > 0) bwd_x(i); bwd_w(i); }
+    a->sq_blocks = 0;
+    if (want_sq && reduce_slabs_n_blocks(js) <= PPO_SQ_PARTIALS) { js.sq_partial = ws + a->w_sqpart; a->sq_blocks = reduce_slabs_n_blocks(js); }
     reduce_slabs_n(js, s);      // every layer has its own slabs: one reduction launch for the whole pass
   } else if (part == 0) {
     head_jobs();
@@ -1548,7 +1621,8 @@ int ppo_begin_update(PpoAlg* a, void* stream) {
 
 }  // extern "C"
 
-static int minibatch_backward(PpoAlg* a, int32_t mb, void* stream, int part) {
+static int minibatch_backward(PpoAlg* a, int32_t mb, void* stream, int part, bool want_sq = false) {
+  if (a) a->sq_blocks = 0;
   if (!a || !a->bound) { pf_set_error("ppo_minibatch_backward: buffers not bound"); return 1; }
   if (ppo_wrong_device(a)) return 1;
   const PpoConfig& c = a->cfg;
@@ -1597,7 +1671,7 @@ static int minibatch_backward(PpoAlg* a, int32_t mb, void* stream, int part) {
                        ws + (a->paired ? a->w_slabl[0][a->actor.nl - 1] : a->w_slabs[0]), ws + (a->paired ? a->w_slabl[1][a->critic.nl - 1] : a->w_slabs[1]),
                        ws + a->w_partial);
     const LossFinish lf{nblk, A, B, c.entropy_coef, ws + a->w_partial, stdp, a->b.d_grads + a->std_off, a->b.d_grads + a->nparams, a->b.d_scalars};
-    if (a->paired) mlp_backward_pair(a, ws + o_xa, ws + o_xc, B, s, a->ld_xa, a->ld_xc, &lf, part);      // finished inside the slab reduction launch
+    if (a->paired) mlp_backward_pair(a, ws + o_xa, ws + o_xc, B, s, a->ld_xa, a->ld_xc, &lf, part, want_sq);      // finished inside the slab reduction launch
     else {
       hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, lf);
       s2 = ppo_fork(a, s);
@@ -1629,6 +1703,23 @@ int ppo_minibatch_backward(PpoAlg* a, int32_t mb, void* stream) { return minibat
 int ppo_minibatch_backward_part(PpoAlg* a, int32_t mb, int32_t part, void* stream) {
   if (part != 0 && part != 1) { pf_set_error("ppo_minibatch_backward_part: part must be 0 or 1"); return 1; }
   return minibatch_backward(a, mb, stream, part);
+}
+
+int ppo_minibatch_step(PpoAlg* a, int32_t mb, void* stream) {
+  if (a && a->cfg.world_size > 1) { pf_set_error("ppo_minibatch_step: one process only (the gradient all-reduce sits between backward and apply)"); return 1; }
+  if (int rc = minibatch_backward(a, mb, stream, -1, true)) return rc;
+  if (a->sq_blocks <= 0) return ppo_minibatch_apply(a, stream);      // (unpaired execution modes: no partials were left)
+  const PpoConfig& c = a->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = a->b.d_workspace;
+  unsigned* ticket = reinterpret_cast<unsigned*>(ws + a->w_sqpart + PPO_SQ_PARTIALS);
+  if (!a->ticket_zeroed) { PPO_HIP_OK(hipMemsetAsync(ticket, 0, sizeof(unsigned), s)); a->ticket_zeroed = true; }
+  hipLaunchKernelGGL(k_adam_fused, dim3(RED_BLOCKS), dim3(256), 0, s, a->nparams, a->b.d_params, a->b.d_grads, a->b.d_adam_m, a->b.d_adam_v,
+                     a->sq_blocks, ws + a->w_sqpart, a->b.d_grads + a->nparams, c.adaptive_schedule, c.desired_kl, c.max_grad_norm,
+                     c.adam_beta1, c.adam_beta2, c.adam_eps, a->b.d_scalars, ticket);
+  a->planes_valid = false;
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
 }
 
 int32_t ppo_supports_parts(const PpoAlg* a) { return a && a->fused_heads && a->paired ? 1 : 0; }

@@ -10,7 +10,7 @@
 #include "../../include/pointfoot_hip.h"
 #include "pf_simt.h"
 
-#define PF_REC_MAX 160
+#define PF_REC_MAX 176
 #define PF_MAXC 6          /* contacts kept per robot (first active in sphere order: feet first): PointFoot.  The quadruped instance keeps
                               PF_MAXC_QUAD = 10 (4 feet x floor + riser face, and two more for a shank or the base): measured on the curriculum field, 0.68 % of its (env, substep)
                               pairs had more than 6 active candidates, PointFoot's 3.4e-5 (profiles/r3_contact_cap.txt) */
@@ -285,16 +285,20 @@ struct PfKernel {
   // Record offsets as compile-time constants (same rule as pf_compute_layout with num_actions == ND; checked against the
   // runtime PfLayout in pf_create): addresses fold into ds_read/ds_write immediates instead of living in SGPRs.
   struct LC {
-    static constexpr int root = 0, dof_pos = root + 13, dof_vel = dof_pos + ND, actions = dof_vel + ND, last_actions = actions + ND,
+    static constexpr int root = 0, dof_pos = root + 13, dof_vel = dof_pos + ND, last_actions = dof_vel + ND,
                          last_dof_vel = last_actions + ND, last_root_vel = last_dof_vel + ND, commands = last_root_vel + 6,
-                         torques = commands + 4, base_lin_vel = torques + ND, base_ang_vel = base_lin_vel + 3,
-                         projected_gravity = base_ang_vel + 3, feet_air_time = projected_gravity + 3,
+                         feet_air_time = commands + 4,
                          last_feet_air_time = feet_air_time + NF, cur_max_feet_height = last_feet_air_time + NF,
                          last_max_feet_height = cur_max_feet_height + NF, feet_height = last_max_feet_height + NF,
                          contact_filt = feet_height + NF, first_contact = contact_filt + NF, last_contacts = first_contact + NF,
-                         contact_forces = last_contacts + NF, feet_pos = contact_forces + 3 * NB, ext_force = feet_pos + 3 * NF,
+                         ext_force = last_contacts + NF,
                          env_origin = ext_force + 4, friction = env_origin + 3, added_mass = friction + 1, added_com = added_mass + 1,
                          lstm_state = added_com + 3, episode_sums = lstm_state + (LR ? 32 * ND : 0);
+    // the write-only part starts on the 64-byte line after the (fixed-size) episode-sum block: a step does not load it
+    static constexpr int rw_floats = (episode_sums + PF_MAX_REWARDS + 1 + 15) & ~15;
+    static constexpr int actions = rw_floats, torques = actions + ND, base_lin_vel = torques + ND, base_ang_vel = base_lin_vel + 3,
+                         projected_gravity = base_ang_vel + 3, contact_forces = projected_gravity + 3,
+                         feet_pos = contact_forces + 3 * NB, rec_used = feet_pos + 3 * NF;
   };
   static bool layout_matches(const PfLayout& L) {
     return L.root == LC::root && L.dof_pos == LC::dof_pos && L.dof_vel == LC::dof_vel && L.actions == LC::actions &&
@@ -306,7 +310,7 @@ struct PfKernel {
            L.first_contact == LC::first_contact && L.last_contacts == LC::last_contacts && L.contact_forces == LC::contact_forces &&
            L.feet_pos == LC::feet_pos && L.ext_force == LC::ext_force && L.env_origin == LC::env_origin && L.friction == LC::friction &&
            L.added_mass == LC::added_mass && L.added_com == LC::added_com && L.lstm_state == LC::lstm_state &&
-           L.episode_sums == LC::episode_sums && L.rec_floats <= REC_MAX;
+           L.episode_sums == LC::episode_sums && L.rw_floats == LC::rw_floats && L.rec_used == LC::rec_used && L.rec_floats <= REC_MAX;
   }
 
   // The robot model, re-packed to this instance's sizes and staged in LDS once per launch: the per-body / per-sphere
@@ -1705,12 +1709,13 @@ struct PfKernel {
         return;
       }
     }
-    PF_LANES(i, L.rec_floats) S[i] = grow[i];
+    // a step (mode 0) reads the read-write part only: everything behind LC::rw_floats is written before it is read
+    { const int nload = g.mode == 0 ? LC::rw_floats : L.rec_floats; PF_LANES(i, nload) S[i] = grow[i]; }
     PF_SYNC();
     if (g.mode == 1) {
       reset_env(sh, m, c, L, B, inj, env, g.step_counter);
       PF_ONE { B.d_episode_length[env] = 0; B.d_reset[env] = 1; }
-      PF_LANES(i, L.rec_floats) grow[i] = S[i];
+      PF_LANES(i, LC::rec_used) grow[i] = S[i];
       return;
     }
     if (g.mode == 2 || g.mode == 3) {      // compute_observations() (:123-129, :320-326): measured_heights are taken afresh (:213 / :324)
@@ -1787,7 +1792,7 @@ struct PfKernel {
     PF_STAMP(sh, 13);
     post_physics(sh, m, c, L, B, inj, env, g.step_counter, DUAL && !inj.d_root);
     PF_STAMP(sh, 14);
-    PF_LANES(i, L.rec_floats) grow[i] = S[i];
+    PF_LANES(i, LC::rec_used) grow[i] = S[i];      // (the padding behind the last field is never written)
     PF_SYNC();
     PF_STAMP(sh, 15);
 #if defined(PF_STAMPS) && !defined(PF_HOST_EMU)

@@ -169,8 +169,16 @@ class PPO:
         self.scalars[SC_VLOSS:SC_SLOSS + 1] = 0.0
         _abi.check(lib.ppo_begin_update(self._h, self._stream()), lib)      # storage into permutation order, once for all epochs
         overlap = dp.collectives_on() and self._grad_groups is not None and os.environ.get("PF_PPO_OVERLAP_ALLREDUCE", "1") != "0"
+        # PF_PPO_FUSED_STEP=1 (one process only): backward + clip + adaptive LR + Adam as ppo_minibatch_step -- the norm's first stage
+        # rides in the slab reduction, the rest is one launch with a last-block ticket: two launches fewer per minibatch.  Measured on
+        # MI355X (profiles/r4_ppo_small_kernel_folds.txt): update 9.99 ms against 9.94 ms with the separate calls -- the launches it
+        # removes were hidden in the queue, the block reductions it adds are not.  Off by default; kept as a tested switch.
+        fused = not dp.collectives_on() and self.world_size == 1 and os.environ.get("PF_PPO_FUSED_STEP", "0") == "1"
         for _epoch in range(self.num_learning_epochs):
             for mb in range(self.num_mini_batches):
+                if fused:
+                    _abi.check(lib.ppo_minibatch_step(self._h, mb, self._stream()), lib)
+                    continue
                 if overlap:
                     # the backward pass in two parts: the all-reduce of the gradients finished by the first (every layer but the
                     # two input layers, std, the KL tail: 90 % of the 1.68 MB for pointfoot_rough) runs over xGMI while the last

@@ -421,3 +421,30 @@ def test_episode_ring_is_the_runners_deque_of_finished_episodes():
         np.testing.assert_allclose(rets, list(rewbuffer), rtol=1e-5, atol=1e-5)
         assert int(alg.ep_ring[3]) == step and int(alg.ep_ring[1]) == len(rewbuffer)
     assert len(rewbuffer) == 100
+
+
+def test_fused_optimiser_step_matches_the_separate_calls(monkeypatch):
+    """ppo_minibatch_step (one process: the gradient norm's first stage inside the slab reduction, clip + adaptive-KL learning rate +
+    Adam as one launch with a last-block ticket) against ppo_minibatch_backward + ppo_minibatch_apply: the same update up to the
+    summation order of the squared norm -- same learning-rate decisions, parameters equal to ~1e-6, Adam step counter and the
+    published scalars (norm, clip coefficient, KL) in place."""
+    N, T, O, P, A, hidden = 128, 8, 27, 148, 6, [512, 256, 128]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PF_PPO_FUSED_STEP", mode)
+        alg, ref = make(N, T, O, P, A, hidden, seed=21)
+        gen = torch.Generator(device="cuda:0").manual_seed(22)
+        fill_rollout(alg, ref, N, T, O, P, A, gen)
+        torch.manual_seed(23)
+        alg.update()
+        torch.cuda.synchronize()
+        out[mode] = (alg.params.clone(), alg.scalars.clone(), alg.adam_m.clone(), alg.adam_v.clone())
+    pf, sf, mf, vf = out["1"]
+    pu, su, mu, vu = out["0"]
+    assert float(sf[0]) == float(su[0]), "adaptive learning rate took a different path"
+    assert float(sf[5]) == float(su[5]) == 20.0 and float(sf[9]) == float(su[9])          # Adam steps / update count
+    torch.testing.assert_close(sf[1:3], su[1:3], rtol=1e-5, atol=1e-7)                     # mean KL, gradient norm of the last minibatch
+    torch.testing.assert_close(pf, pu, rtol=0, atol=2e-6)
+    torch.testing.assert_close(mf, mu, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(vf, vu, rtol=1e-4, atol=1e-9)
+    assert not torch.equal(pf, torch.zeros_like(pf))

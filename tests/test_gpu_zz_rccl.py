@@ -29,6 +29,9 @@ def _update(seed=11):
 
 def test_update_through_a_single_rank_rccl_group_is_the_plain_update(monkeypatch):
     from pointfoot_amd import dp
+    # the reference run takes the separate backward / apply calls too (ppo_minibatch_step, PF_PPO_FUSED_STEP=1, sums the squared
+    # gradient norm in another order: tests/test_gpu_ppo.py compares the two)
+    monkeypatch.setenv("PF_PPO_FUSED_STEP", "0")
     base_params, base_lr, base_adv = _update()
     assert not dp.collectives_on()
     with socket.socket() as s:

@@ -24,8 +24,14 @@ int main(int argc, char** argv) {
   g.A = A; g.C = Cm; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.bias = bias; g.H = H; g.ldh = N;
   g.Bp = Bp; g.ldbp = ldbp; g.bplane = (long long)N * ldbp;
   const bool pair = argc > 7 && atoi(argv[7]) != 0;
+#if G3F_EMIT_PLANES
+  { unsigned short* Cp; OK(hipMalloc(&Cp, (size_t)3 * M * N * 2)); g.Cp = Cp; g.cplane = (long long)M * N; }
+#endif
   GemmArgs g2 = g;
   if (pair) { float* C2; OK(hipMalloc(&C2, (size_t)M * N * 4)); g2.C = C2; }
+#if G3F_EMIT_PLANES
+  if (pair) { unsigned short* Cp2; OK(hipMalloc(&Cp2, (size_t)3 * M * N * 2)); g2.Cp = Cp2; }
+#endif
   hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
   auto launch = [&]() {
     if (pair) { if (mode == 0) pf_gemm3f_launch2<GEMM_EPI_BIAS_ELU>(g, g2, 0, bn); else pf_gemm3f_launch2<GEMM_EPI_MUL_DELU>(g, g2, 0, bn); }
@@ -39,6 +45,6 @@ int main(int argc, char** argv) {
   for (int i = 0; i < iters; ++i) launch();
   OK(hipEventRecord(e1, 0)); OK(hipEventSynchronize(e1));
   float ms; OK(hipEventElapsedTime(&ms, e0, e1));
-  printf("ablate %2d mode %d M=%d N=%d K=%d bn %d%s%s: %.1f us\n", G3F_ABLATE, mode, M, N, K, bn, zeros ? " zeros" : "", pair ? " pair" : "", ms * 1000.0f / iters);
+  printf("ablate %2d%s mode %d M=%d N=%d K=%d bn %d%s%s: %.1f us\n", G3F_ABLATE, G3F_EMIT_PLANES ? " +planes" : "", mode, M, N, K, bn, zeros ? " zeros" : "", pair ? " pair" : "", ms * 1000.0f / iters);
   return 0;
 }
