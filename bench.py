@@ -113,7 +113,9 @@ PPO_MFLOP_PER_ENV_STEP = 13.4  # 0.84 rollout + 12.5 update
 # HBM bytes per step-kernel launch come from the committed rocprofv3 PMC summary of THIS kernel (tools/pmc_traffic.py
 # writes it from separate --pmc passes, with the guide's gfx950 corrections); used only when kernel, task and env count match.
 TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", f) for f in
-                    ("r3_step_kernel_hbm_pmc.json", "r3_step_kernel_hbm_pmc_anymal_c_rough.json", "r2_step_kernel_hbm_pmc.json")]
+                    ("r4_step_kernel_hbm_pmc.json", "r4_step_kernel_hbm_pmc_anymal_c_rough.json")]      # profiles of the kernels as they are NOW
+# (older summaries -- r3_step_kernel_hbm_pmc*.json, r2_... -- describe kernels that no longer exist: single-wavefront PointFoot instance,
+# whole-record loads; they are not offered as this build's traffic)
 
 
 def step_traffic(kernel_prefix, task, num_envs):
@@ -513,7 +515,8 @@ def main():
         ach_tf = upd_flop / (upd_ms * 1e-3) / 1e12
         headline = a.task == "pointfoot_rough" and a.num_envs == NUM_ENVS
         dims = lambda d: "-".join(str(v) for v in d)
-        kern = "pf_step_kernel<17,12,4,LeggedRobot>" if anymal else "pf_step_kernel<9,6,2,PointFoot>"
+        kern = ("pf_step_kernel<17,12,4,LeggedRobot> (one wavefront per robot, four robots per workgroup)" if anymal
+                else "pf_step_kernel<9,6,2,PointFoot,DUAL> (two wavefronts per pair of robots: dynamics beside contacts)")
         widest = max(max(ac.actor_dims[1:-1]), max(ac.critic_dims[1:-1]))
         env_gemm = os.environ.get("PF_PPO_GEMM")           # set by --gemm; unset: the library picks by width (ppo_create)
         x6 = env_gemm == "2" or (env_gemm is None and widest >= 256)
