@@ -1662,7 +1662,8 @@ struct PfKernel {
   // needed, so PF_SYNC stays wave-local and robots of one workgroup may diverge freely).
   // role (DUAL instances): 0 = the wavefront that runs the step (alone: every other instance), 1 = its partner, which runs the
   // contact side of every substep and nothing else
-  PF_DEV void run(Shared& sh, SharedRO& ro, const PfStepArgs& g, int env, int role = 0) {
+  // shv / slot (DUAL): the workgroup's array of per-robot blocks and this robot's index in it -- see the substep loop
+  PF_DEV void run(Shared& sh, SharedRO& ro, const PfStepArgs& g, int env, int role = 0, Shared* shv = nullptr, int slot = 0) {
     const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
     ModelS& ms = ro.mdl;
     if constexpr (DUAL) { if (role == 1 && (g.mode != 0 || inj.d_root)) return; }      // no substeps: nothing for the partner to do
@@ -1762,13 +1763,21 @@ struct PfKernel {
         if (pd) torques(sh, c, L, S + LC::dof_pos, 1, LC::dof_vel - LC::dof_pos);
         PF_STAMP(sh, 12);
         bool ext = sub == 0 && S[LC::ext_force + 3] != 0.0f;
+        // register-starved instances (PF_OPAQUE_LANE): the block's LDS address is formed again in every substep behind an opaque copy
+        // of the slot index, so that nothing derived from it (base + array offset, + lane stride ...) is hoisted above the loop and
+        // carried -- spilled -- across it
+        int slot2 = slot;
+#if !defined(PF_HOST_EMU)
+        if constexpr (PF_OPAQUE_LANE) asm volatile("" : "+v"(slot2));
+#endif
+        Shared& shl = (PF_OPAQUE_LANE && shv) ? shv[slot2] : sh;
         if constexpr (DUAL) {
           float Lr[NLT], dv[NDV];
-          substep_dyn(sh, m, c, L, B, ext, env, Lr, dv, sub + 1);
+          substep_dyn(shl, m, c, L, B, ext, env, Lr, dv, sub + 1);
           PF_XSYNC();                        // ... and has finished it
           PF_STAMP(sh, 5);
-          substep_solve(sh, m, c, L, B, env, sub, sh.ncon_x, Lr, dv);
-        } else substep(sh, m, c, L, B, ext, env, sub, ix0, iy0);
+          substep_solve(shl, m, c, L, B, env, sub, shl.ncon_x, Lr, dv);
+        } else substep(shl, m, c, L, B, ext, env, sub, ix0, iy0);
         if (ext) { PF_ONE { S[LC::ext_force + 3] = 0.0f; } PF_SYNC(); }
       }
       {
@@ -1790,9 +1799,18 @@ struct PfKernel {
       PF_SYNC();
     }
     PF_STAMP(sh, 13);
-    post_physics(sh, m, c, L, B, inj, env, g.step_counter, DUAL && !inj.d_root);
+    // (everything behind the substeps addresses global memory through an opaque copy of the env index: row pointers are formed
+    // here, where they are used, instead of ahead of the loop and carried -- spilled -- across it)
+    int env2 = env;
+#if !defined(PF_HOST_EMU)
+    if constexpr (PF_OPAQUE_LANE) asm volatile("" : "+v"(env2));
+#endif
+    post_physics(sh, m, c, L, B, inj, env2, g.step_counter, DUAL && !inj.d_root);
     PF_STAMP(sh, 14);
-    PF_LANES(i, LC::rec_used) grow[i] = S[i];      // (the padding behind the last field is never written)
+    {
+      float* grow2 = B.d_state + (size_t)env2 * L.rec_floats;
+      PF_LANES(i, LC::rec_used) grow2[i] = S[i];      // (the padding behind the last field is never written)
+    }
     PF_SYNC();
     PF_STAMP(sh, 15);
 #if defined(PF_STAMPS) && !defined(PF_HOST_EMU)

@@ -5,7 +5,7 @@
 # usage: bash tools/profile_round.sh <tag> [parts]     parts: any of bench trace hbm stepmix gemm anymal flat (default: all)
 #   -> gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
 set -e
-TAG=${1:-r3}
+TAG=${1:-r4}
 PARTS=${2:-"bench trace hbm stepmix gemm anymal flat"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out

@@ -9,7 +9,9 @@ import __graft_entry__ as ge
 def main():
     prefix, extra = sys.argv[1], sys.argv[2:]
     fl = ge.build_flags()
-    cmd = fl["common"] + fl["per_source"].get("pf_env.hip", []) + extra + ["--cuda-device-only", "-gline-tables-only", "-S", "-o", "-", os.path.join(ge.CSRC, "pf_env.hip")]
+    src = "pf_env_quad.hip" if "ILi17E" in prefix else "pf_env.hip"
+    per = [] if os.environ.get("SCHED") == "none" else fl["per_source"].get(src, [])
+    cmd = fl["common"] + per + extra + ["--cuda-device-only", "-gline-tables-only", "-S", "-o", "-", os.path.join(ge.CSRC, src)]
     asm = subprocess.run(cmd, cwd=ROOT, check=True, capture_output=True, text=True).stdout.split("\n")
     files = {}
     for l in asm:

@@ -7,8 +7,9 @@ sys.path.insert(0, ROOT)
 lib_dbg = os.path.join(ROOT, "gpurun_out", "libpointfoot_hip_stamps.so")
 os.makedirs(os.path.dirname(lib_dbg), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-mllvm", "-inline-threshold=225",
-                       "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-fPIC", "-shared", "-DPF_STAMPS", *os.environ.get("PF_EXTRA_FLAGS", "").split(), "-o", lib_dbg,
-                       os.path.join(ROOT, "pointfoot_amd/csrc/pf_env.hip"), os.path.join(ROOT, "pointfoot_amd/csrc/pf_ppo.hip")])
+                       "-fPIC", "-shared", "-DPF_STAMPS", *os.environ.get("PF_EXTRA_FLAGS", "").split(), "-o", lib_dbg,
+                       os.path.join(ROOT, "pointfoot_amd/csrc/pf_env.hip"), os.path.join(ROOT, "pointfoot_amd/csrc/pf_env_quad.hip"),
+                       os.path.join(ROOT, "pointfoot_amd/csrc/pf_ppo.hip")])
 from pointfoot_amd import _abi
 _abi.lib_path = lambda: lib_dbg
 import torch
