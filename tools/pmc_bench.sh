@@ -10,4 +10,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   rocprofv3 --pmc $set --output-format csv -d $O/${TAG}_pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_alt "$@" > $O/${TAG}_pmc$i.log 2>&1
   f=$(find $O/${TAG}_pmc$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 $R/tools/pmc_summary.py $f "$PAT"
+  rm -rf $O/${TAG}_pmc$i          # (raw per-dispatch rows: tens of MB; gpurun carries at most 64 MiB back)
 done

@@ -9,4 +9,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   rocprofv3 --pmc $set --output-format csv -d $O/${TAG}_pmc$i -- python3 $R/tools/step_bench.py $N 40 $TASK > $O/${TAG}_pmc$i.log 2>&1
   f=$(find $O/${TAG}_pmc$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 $R/tools/pmc_summary.py $f pf_step_kernel | tail -8
+  rm -rf $O/${TAG}_pmc$i
 done

@@ -19,6 +19,7 @@ fi
 if has trace; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 $R/bench.py --steps 10 --warmup 3 --no_cpu_baseline > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof.err
   find $O/${TAG}_prof -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_bench_kernel_stats.csv \;
+  rm -rf $O/${TAG}_prof             # (the raw trace is tens of MB; gpurun carries at most 64 MiB back)
   head -14 $O/${TAG}_bench_kernel_stats.csv | cut -c1-160
 fi
 if has hbm; then
@@ -28,6 +29,7 @@ if has hbm; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch_q -- python3 $R/tools/step_bench.py 8192 40 anymal_c_rough > $O/${TAG}_pmc_fetch_q.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write_q -- python3 $R/tools/step_bench.py 8192 40 anymal_c_rough > $O/${TAG}_pmc_write_q.log 2>&1
   python3 $R/tools/pmc_traffic.py $O/${TAG}_pmc_fetch_q $O/${TAG}_pmc_write_q "pf_step_kernel<17" anymal_c_rough 8192 $O/${TAG}_step_kernel_hbm_pmc_anymal_c_rough.json
+  rm -rf $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_fetch_q $O/${TAG}_pmc_write_q
 fi
 if has stepmix; then
   bash $R/tools/pmc_step.sh ${TAG}_step 4096 pointfoot_rough > $O/${TAG}_step_kernel_pmc_raw.txt 2>&1
