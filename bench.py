@@ -539,8 +539,10 @@ def main():
                        "finite": finite},
             "ranks_in_lockstep": lockstep,
             # named from the process group itself (dp.backend_name: "nccl" = RCCL), not from the flag
-            "collectives": ((f"{dp_backend}, group of ONE rank with every collective of the N>1 path issued (PF_DP_SINGLE_RANK_COLLECTIVES=1 rehearsal)" if rehearse1
-                             else f"{dp_backend}, {world} ranks") if dist_on else None),
+            "collectives": (((f"{dp_backend}, group of ONE rank with every collective of the N>1 path issued (PF_DP_SINGLE_RANK_COLLECTIVES=1 rehearsal)" if rehearse1
+                              else f"{dp_backend}, {world} ranks")
+                             + ("; gradient all-reduce: two asynchronous ranges under the split backward pass" if os.environ.get("PF_PPO_OVERLAP_ALLREDUCE", "0") == "1"
+                                else "; gradient all-reduce: one blocking call per minibatch")) if dist_on else None),
             "alt_fp32_mfma": alt,
             "roofline": {"kernel": kern + " (fused env step)", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,

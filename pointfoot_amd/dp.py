@@ -147,7 +147,10 @@ def init_process_group(backend="nccl", local_rank=None):
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, device_id=torch.device(f"cuda:{local_rank}"))
+        if os.environ.get("PF_DP_NO_DEVICE_ID") == "1":      # (A/B switch: the unbound form of rounds 1-3)
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group(backend, device_id=torch.device(f"cuda:{local_rank}"))
     else:
         dist.init_process_group(backend)
     return world()

@@ -168,7 +168,12 @@ class PPO:
         self.perm.copy_(torch.randperm(n, device=self.device).to(torch.int32))
         self.scalars[SC_VLOSS:SC_SLOSS + 1] = 0.0
         _abi.check(lib.ppo_begin_update(self._h, self._stream()), lib)      # storage into permutation order, once for all epochs
-        overlap = dp.collectives_on() and self._grad_groups is not None and os.environ.get("PF_PPO_OVERLAP_ALLREDUCE", "1") != "0"
+        # PF_PPO_OVERLAP_ALLREDUCE=1: the backward pass in two parts with an asynchronous all-reduce behind each.  Default OFF since
+        # round 4: on a one-rank RCCL group (every collective issued, nothing to move) the split costs +0.95 ms per update against
+        # +0.13 ms for ONE blocking all-reduce per minibatch (profiles/r4_bench_rccl_single_rank*.json) -- four cross-stream hand-overs and
+        # a second slab reduction per minibatch; what it could hide on 8 GPUs (20 x ~40 us of a 1.68 MB ring all-reduce) is no larger.
+        # To be re-decided on a node with more than one GPU.
+        overlap = dp.collectives_on() and self._grad_groups is not None and os.environ.get("PF_PPO_OVERLAP_ALLREDUCE", "0") == "1"
         # PF_PPO_FUSED_STEP=1 (one process only): backward + clip + adaptive LR + Adam as ppo_minibatch_step -- the norm's first stage
         # rides in the slab reduction, the rest is one launch with a last-block ticket: two launches fewer per minibatch.  Measured on
         # MI355X (profiles/r4_ppo_small_kernel_folds.txt): update 9.99 ms against 9.94 ms with the separate calls -- the launches it
