@@ -348,7 +348,8 @@ typedef struct PpoBuffers {
   int64_t workspace_floats;
   float* d_ep_return;  /* [N] running undiscounted return of the current episode (runner statistics), or NULL */
   float* d_ep_length;  /* [N] running length of the current episode, or NULL */
-  float* d_ep_stats;   /* [4]: sum of finished-episode returns, sum of their lengths, count (since the host last zeroed it) */
+  float* d_ep_stats;   /* [4]: sum of finished-episode returns, sum of their lengths, count (since the host last zeroed it); added to
+                          by every ppo_process_env_step, or -- with d_ep_fin and d_ep_ring bound -- once per rollout by ppo_compute_returns */
   float* d_ep_fin;     /* [2,T,N] or NULL: undiscounted return and length of the episode that ended at (t, env); written where done */
   int32_t* d_ep_ring;  /* [PPO_EP_RING_INTS] or NULL: the last PPO_EP_RING finished episodes in (step, env) order -- what rsl_rl's
                           OnPolicyRunner keeps in rewbuffer / lenbuffer = deque(maxlen=100) (call site legged_gym/scripts/train.py:44).
@@ -383,6 +384,13 @@ int ppo_act_inference(PpoAlg* alg, const float* d_obs, int32_t n, float* d_actio
 /* PPO.process_env_step: rewards += gamma * value * time_outs; store rewards / dones for step t */
 int ppo_process_env_step(PpoAlg* alg, int32_t t, const float* d_rew, const uint8_t* d_dones,
                          const uint8_t* d_time_outs, void* stream);
+/* The same transition processing, carried out in the tail of the NEXT ppo_act's head kernel (or by ppo_compute_returns / the next
+ * ppo_process_env_step*, whichever is enqueued first) instead of a launch of its own.  The caller promises that the three input
+ * buffers keep this step's values until that call has been enqueued on the same stream -- true of an env whose step outputs are
+ * persistent buffers rewritten only by its next step (OnPolicyRunner: act -> env.step -> process_env_step -> act ...).  Storage
+ * rows d_rewards / d_dones of step t and the episode bookkeeping are defined only after that later call. */
+int ppo_process_env_step_deferred(PpoAlg* alg, int32_t t, const float* d_rew, const uint8_t* d_dones,
+                                  const uint8_t* d_time_outs, void* stream);
 /* PPO.compute_returns: critic(last_critic_obs), GAE reverse scan, advantage normalisation.
  * With world_size > 1 the host all-reduces d_scalars[10..12] (sum, sumsq, count) between the two halves. */
 int ppo_compute_returns(PpoAlg* alg, const float* d_last_critic_obs, void* stream);

@@ -201,6 +201,7 @@ def _bind_ppo(lib):
     lib.ppo_act.argtypes = [vp, i32, vp, vp, vp, C.c_int64, vp, vp]
     lib.ppo_act_inference.argtypes = [vp, vp, i32, vp, vp]
     lib.ppo_process_env_step.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.ppo_process_env_step_deferred.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.ppo_compute_returns.argtypes = [vp, vp, vp]
     lib.ppo_normalize_advantages.argtypes = [vp, vp]
     lib.ppo_minibatch_backward.argtypes = [vp, i32, vp]
@@ -213,7 +214,7 @@ def _bind_ppo(lib):
     lib.ppo_grad_groups.restype = i32
     lib.ppo_supports_parts.argtypes = [vp]
     lib.ppo_supports_parts.restype = i32
-    for fn in ("ppo_bind_buffers", "ppo_act", "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns",
+    for fn in ("ppo_bind_buffers", "ppo_act", "ppo_act_inference", "ppo_process_env_step", "ppo_process_env_step_deferred", "ppo_compute_returns",
                "ppo_normalize_advantages", "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_apply", "ppo_minibatch_step"):
         getattr(lib, fn).restype = i32
 
@@ -228,5 +229,5 @@ EXPORTED_SYMBOLS = [
     "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers", "pf_set_reset_stats", "pf_set_reset_stats_next", "pf_measure_heights",
     "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations",
     "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act",
-    "ppo_act_inference", "ppo_process_env_step", "ppo_compute_returns", "ppo_normalize_advantages",
+    "ppo_act_inference", "ppo_process_env_step", "ppo_process_env_step_deferred", "ppo_compute_returns", "ppo_normalize_advantages",
     "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_backward_part", "ppo_grad_groups", "ppo_supports_parts", "ppo_minibatch_apply", "ppo_minibatch_step"]

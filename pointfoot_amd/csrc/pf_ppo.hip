@@ -90,6 +90,41 @@ __global__ void k_sample(int N, int A, int O, int P, const float* __restrict__ o
   s_val[i] = value[i]; s_logp[i] = lp;
 }
 
+// PPO.process_env_step for one env: bootstrap on time-outs, store reward / done, the runner's episode bookkeeping.  Runs either as
+// its own launch (k_process) or, for a step whose env outputs stay in place until then (ppo_process_env_step_deferred), in the tail
+// of the NEXT transition's k_act_heads -- one launch fewer per policy step.
+struct ProcArgs {
+  const float* rew; const uint8_t* dones; const uint8_t* time_outs; const float* s_val;
+  float *s_rew, *s_done, *ep_ret, *ep_len, *ep_stats, *fin_ret, *fin_len;
+  float gamma;
+};
+// in two halves, so that a host kernel can issue the loads long before it needs them
+struct ProcIn { float r, er, el, v; bool done, to; };
+__device__ __forceinline__ ProcIn process_load(const ProcArgs& p, int i) {
+  ProcIn x;
+  x.r = p.rew[i]; x.done = p.dones[i] != 0;
+  x.er = p.ep_ret ? p.ep_ret[i] : 0.0f; x.el = p.ep_ret ? p.ep_len[i] : 0.0f;
+  x.to = p.time_outs ? p.time_outs[i] != 0 : false; x.v = p.time_outs ? p.s_val[i] : 0.0f;
+  return x;
+}
+__device__ __forceinline__ void process_store(const ProcArgs& p, int i, const ProcIn& x) {
+  float r = x.r;
+  if (p.ep_ret) {     // OnPolicyRunner bookkeeping (cur_reward_sum / cur_episode_length / rewbuffer), kept on the device
+    float cr = x.er + r, cl = x.el + 1.0f;
+    if (x.done) {
+      // with the finished-episode arrays bound, k_episode_ring sums them into ep_stats once per rollout (in a fixed order); ~100
+      // same-address atomics per step otherwise -- they were most of this kernel's 4.9 us
+      if (p.fin_ret) { p.fin_ret[i] = cr; p.fin_len[i] = cl; }
+      else { atomicAdd(p.ep_stats, cr); atomicAdd(p.ep_stats + 1, cl); atomicAdd(p.ep_stats + 2, 1.0f); }
+      cr = 0.0f; cl = 0.0f;
+    }
+    p.ep_ret[i] = cr; p.ep_len[i] = cl;
+  }
+  if (p.time_outs) r += p.gamma * (x.v * (x.to ? 1.0f : 0.0f));
+  p.s_rew[i] = r; p.s_done[i] = x.done ? 1.0f : 0.0f;
+}
+__device__ __forceinline__ void process_body(const ProcArgs& p, int i) { process_store(p, i, process_load(p, i)); }
+
 // k_thin_fwd (both heads) + k_sample in one launch for the rollout: 8 lanes per env compute the action means and the
 // value from the last hidden activations, then lane k of the group draws action dimension k (same Philox keys as k_sample).
 __global__ __launch_bounds__(256) void k_act_heads(int N, int A, int O, int P, int Ka, int Kc, const float* __restrict__ obs,
@@ -100,7 +135,7 @@ __global__ __launch_bounds__(256) void k_act_heads(int N, int A, int O, int P, i
                                                    const float* __restrict__ inject_normal, uint32_t k0, uint32_t k1, uint32_t counter,
                                                    uint32_t env_base, float* __restrict__ actions_out, float* __restrict__ s_obs,
                                                    float* __restrict__ s_cobs, float* __restrict__ s_act, float* __restrict__ s_val,
-                                                   float* __restrict__ s_logp, float* __restrict__ s_mu, float* __restrict__ s_sigma) {
+                                                   float* __restrict__ s_logp, float* __restrict__ s_mu, float* __restrict__ s_sigma, ProcArgs prev) {
   extern __shared__ __attribute__((aligned(16))) float asm_[];
   float* sWa = asm_;               // [A][Ka]
   float* sWc = sWa + A * Ka;       // [Kc]
@@ -115,6 +150,8 @@ __global__ __launch_bounds__(256) void k_act_heads(int N, int A, int O, int P, i
   const int lane8 = threadIdx.x & 7;
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
   if (i >= N) return;                 // whole 8-lane groups leave together (shuffles below stay inside a group)
+  ProcIn pin{};
+  if (prev.rew && lane8 == 0) pin = process_load(prev, i);      // the previous transition's deferred process_env_step: loads now, rest at the end
   float mu[16], val = 0.0f;
 #pragma unroll
   for (int o = 0; o < 16; ++o) mu[o] = 0.0f;
@@ -175,67 +212,96 @@ __global__ __launch_bounds__(256) void k_act_heads(int N, int A, int O, int P, i
     }
   }
   lp += __shfl_xor(lp, 1, 64); lp += __shfl_xor(lp, 2, 64); lp += __shfl_xor(lp, 4, 64);
-  if (lane8 == 0) { s_val[i] = val; s_logp[i] = lp; }
+  if (lane8 == 0) {
+    s_val[i] = val; s_logp[i] = lp;
+    if (prev.rew) process_store(prev, i, pin);
+  }
 }
 
-// PPO.process_env_step: bootstrap on time-outs, store reward / done
-__global__ void k_process(int N, float gamma, const float* __restrict__ rew, const uint8_t* __restrict__ dones,
-                          const uint8_t* __restrict__ time_outs, const float* __restrict__ s_val, float* __restrict__ s_rew,
-                          float* __restrict__ s_done, float* __restrict__ ep_ret, float* __restrict__ ep_len, float* __restrict__ ep_stats,
-                          float* __restrict__ fin_ret, float* __restrict__ fin_len) {
+__global__ void k_process(int N, ProcArgs p) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  float r = rew[i];
-  bool done = dones[i] != 0;
-  if (ep_ret) {     // OnPolicyRunner bookkeeping (cur_reward_sum / cur_episode_length / rewbuffer), kept on the device
-    float cr = ep_ret[i] + r, cl = ep_len[i] + 1.0f;
-    if (done) {
-      atomicAdd(ep_stats, cr); atomicAdd(ep_stats + 1, cl); atomicAdd(ep_stats + 2, 1.0f);
-      if (fin_ret) { fin_ret[i] = cr; fin_len[i] = cl; }      // picked up by k_episode_ring at the end of the rollout
-      cr = 0.0f; cl = 0.0f;
-    }
-    ep_ret[i] = cr; ep_len[i] = cl;
-  }
-  if (time_outs) r += gamma * (s_val[i] * (time_outs[i] ? 1.0f : 0.0f));
-  s_rew[i] = r; s_done[i] = done ? 1.0f : 0.0f;
+  if (i < N) process_body(p, i);
 }
 
 // rsl_rl OnPolicyRunner.learn: `rewbuffer.extend(cur_reward_sum[new_ids])`, `lenbuffer.extend(cur_episode_length[new_ids])` with
 // deque(maxlen=100) -- the last 100 FINISHED EPISODES in (step, env index) order.  One launch per rollout, one workgroup: a scan over
 // the rollout's T*N done flags in that order appends the finished episodes to a ring of PPO_EP_RING entries in device memory; no
 // host synchronisation, the runner reads the ring only when it logs.
-__global__ void __launch_bounds__(1024) k_episode_ring(int N, int T, const float* __restrict__ s_done, const float* __restrict__ fin,
-                                                       int* __restrict__ ring) {
-  __shared__ int cnt[1024];
-  const int tid = threadIdx.x;
-  const size_t n = (size_t)N * T, per = (n + 1023) / 1024;
-  const size_t lo = (size_t)tid * per < n ? (size_t)tid * per : n, hi = lo + per < n ? lo + per : n;
-  int c = 0;
-  for (size_t i = lo; i < hi; ++i) c += s_done[i] != 0.0f;
-  cnt[tid] = c;
+// Two launches per rollout.  k_episode_chunks: the T*N flags in chunks of EP_CHUNK-multiples, one workgroup per chunk -- count of
+// finished episodes, sum of their returns and of their lengths (the runner's ep_stats) into part[4 b ..].  k_episode_ring: one
+// workgroup of sixteen wavefronts; every wavefront takes one of the LAST chunks (its number of episodes "behind" comes from the chunk
+// counts), reads it backwards 512 flags at a time with eight independent coalesced loads and writes the episodes that are among the
+// last PPO_EP_RING of the rollout -- of ~2000 finished episodes per rollout only the last 100 can stay, so ~5 000 of the 98 304
+// flags are read a second time.  (The first versions walked all flags in one workgroup with one dependent load per iteration: 90 us.)
+constexpr int EP_CHUNK = 512;
+__device__ __forceinline__ float block_sum(float v, float* sm);
+__host__ __device__ inline long long ep_chunk_len(long long n) { return (long long)EP_CHUNK * ((n + (long long)EP_CHUNK * 1024 - 1) / ((long long)EP_CHUNK * 1024)); }
+__global__ void __launch_bounds__(256) k_episode_chunks(long long n, long long chunk, const float* __restrict__ s_done, const float* __restrict__ fin,
+                                                        float* __restrict__ part) {
+  __shared__ float sm[8];
+  const long long lo = (long long)blockIdx.x * chunk;
+  float c = 0.0f, sr = 0.0f, sl = 0.0f;
+  for (long long k = threadIdx.x; k < chunk; k += 256) {
+    const long long i = lo + k;
+    if (i < n && s_done[i] != 0.0f) { c += 1.0f; sr += fin[i]; sl += fin[n + i]; }
+  }
+  c = block_sum(c, sm); sr = block_sum(sr, sm); sl = block_sum(sl, sm);
+  if (threadIdx.x == 0) { part[4 * blockIdx.x] = c; part[4 * blockIdx.x + 1] = sr; part[4 * blockIdx.x + 2] = sl; }
+}
+__global__ void __launch_bounds__(1024) k_episode_ring(int N, int T, long long chunk, int nchunks, const float* __restrict__ s_done,
+                                                       const float* __restrict__ fin, const float* __restrict__ part, int* __restrict__ ring,
+                                                       float* __restrict__ ep_stats) {
+  __shared__ int cnt[1024];                   // episodes per chunk (nchunks <= 1024), then their inclusive suffix sums
+  __shared__ float sums[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long long n = (long long)N * T;
+  cnt[tid] = tid < nchunks ? (int)part[4 * tid] : 0;
+  float sr = tid < nchunks ? part[4 * tid + 1] : 0.0f, sl = tid < nchunks ? part[4 * tid + 2] : 0.0f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sr += __shfl_xor(sr, o, 64); sl += __shfl_xor(sl, o, 64); }
+  if (lane == 0) { sums[0][w] = sr; sums[1][w] = sl; }
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    int v = tid >= d ? cnt[tid - d] : 0;
+  for (int d = 1; d < 1024; d <<= 1) {        // cnt[b] := episodes in chunks b .. nchunks-1
+    const int v = tid + d < 1024 ? cnt[tid + d] : 0;
     __syncthreads();
     cnt[tid] += v;
     __syncthreads();
   }
-  const int tot = cnt[1023];
-  int p = cnt[tid] - c;
+  const int tot = cnt[0];
   const int head = ring[0], count = ring[1], seq = ring[2], step0 = ring[3];
-  __syncthreads();
-  for (size_t i = lo; i < hi; ++i) {
-    if (s_done[i] != 0.0f) {
-      if (p >= tot - PPO_EP_RING) {       // of more than PPO_EP_RING episodes in one rollout only the last ones can stay
-        int* e = ring + 4 + 4 * ((head + p) % PPO_EP_RING);
-        e[0] = __float_as_int(fin[i]); e[1] = __float_as_int(fin[n + i]); e[2] = step0 + (int)(i / N); e[3] = seq + p;
+  __syncthreads();                            // every wavefront has the header before thread 0 rewrites it
+  for (int b = nchunks - 1 - w; b >= 0; b -= 16) {
+    int behind = b + 1 < nchunks ? cnt[b + 1] : 0;
+    if (behind >= PPO_EP_RING) break;         // (suffix counts only grow towards the front: nothing further ahead can qualify)
+    if (cnt[b] == behind) continue;           // no episode ended in this chunk
+    for (long long hi = chunk; hi > 0 && behind < PPO_EP_RING; hi -= EP_CHUNK) {
+      const long long base = (long long)b * chunk + hi - EP_CHUNK;
+      float dn[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const long long i = base + 64 * k + lane; dn[k] = i < n ? s_done[i] : 0.0f; }
+#pragma unroll
+      for (int k = 7; k >= 0; --k) {
+        const long long i = base + 64 * k + lane;
+        const bool d = dn[k] != 0.0f;
+        const unsigned long long m = __ballot(d);
+        if (d) {
+          const int rev = behind + __popcll(m >> lane) - 1;     // finished episodes behind this one in (step, env) order
+          if (rev < PPO_EP_RING) {
+            const int p = tot - 1 - rev;
+            int* e = ring + 4 + 4 * ((head + p) % PPO_EP_RING);
+            e[0] = __float_as_int(fin[i]); e[1] = __float_as_int(fin[n + i]); e[2] = step0 + (int)(i / N); e[3] = seq + p;
+          }
+        }
+        behind += __popcll(m);
       }
-      ++p;
     }
   }
   if (tid == 0) {
     ring[0] = (head + tot) % PPO_EP_RING; ring[1] = count + tot < PPO_EP_RING ? count + tot : PPO_EP_RING;
     ring[2] = seq + tot; ring[3] = step0 + T;
+    float tr = 0.0f, tl = 0.0f;
+    for (int k = 0; k < 16; ++k) { tr += sums[0][k]; tl += sums[1][k]; }
+    ep_stats[0] += tr; ep_stats[1] += tl; ep_stats[2] += (float)tot;
   }
 }
 
@@ -280,11 +346,13 @@ __global__ void k_moments1(size_t n, const float* __restrict__ x, float* __restr
   if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s; partial[2 * blockIdx.x + 1] = q; }
 }
 __global__ void k_moments2(int nb, size_t n, const float* __restrict__ partial, float* __restrict__ scalars) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nb; ++b) { s += partial[2 * b]; q += partial[2 * b + 1]; }
-    scalars[SC_ADV_SUM] = (float)s; scalars[SC_ADV_SUMSQ] = (float)q; scalars[SC_ADV_CNT] = (float)n;
-  }
+  // one wavefront: lane-strided double sums, then a butterfly (a fixed order; one thread walking the 240 partials took 14 us)
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  double s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 64) { s += partial[2 * b]; q += partial[2 * b + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if (threadIdx.x == 0) { scalars[SC_ADV_SUM] = (float)s; scalars[SC_ADV_SUMSQ] = (float)q; scalars[SC_ADV_CNT] = (float)n; }
 }
 // advantages = (adv - mean) / (std + 1e-8), torch.std is unbiased; sums may have been all-reduced by the host
 __global__ void k_normalize(size_t n, float* __restrict__ x, float* __restrict__ scalars) {
@@ -969,6 +1037,8 @@ struct PpoAlg {
   bool dma = true;         // bf16x6 forward / data-gradient GEMMs on the LDS-DMA kernel (pf_gemm3f.h) where shapes allow
   bool split3 = true;      // dense layers on the bf16 matrix pipes by exact three-way operand split (pf_gemm3.h); false: fp32 MFMA
   int max_rows = 0, max_width = 0, splits = 0;
+  bool pend = false;       // a deferred process_env_step waits for the next ppo_act / ppo_compute_returns
+  ProcArgs pend_args{};
 };
 
 // layers [lo, hi) of one network into the flat buffer
@@ -1486,9 +1556,11 @@ int ppo_bind_buffers(PpoAlg* a, const PpoBuffers* b) {
                        b->d_values, b->d_returns, b->d_advantages, b->d_log_prob, b->d_mu, b->d_sigma, b->d_perm, b->d_workspace, b->d_scalars};
   for (const void* p : req) if (!p) { pf_set_error("ppo_bind_buffers: a required buffer is NULL"); return 1; }
   if (b->workspace_floats < (int64_t)a->w_total) { pf_set_error("ppo_bind_buffers: workspace too small (see ppo_workspace_floats)"); return 1; }
-  a->b = *b; a->bound = true; a->planes_valid = false;
+  a->b = *b; a->bound = true; a->planes_valid = false; a->pend = false;
   return 0;
 }
+
+static void ppo_flush_process(PpoAlg* a, hipStream_t s);
 
 int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs, float* d_actions_out, int64_t sample_counter,
             const float* d_inject_normal, void* stream) {
@@ -1520,8 +1592,10 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
                        a->b.d_params + La.w, a->b.d_params + La.b, a->b.d_params + Lc.w, a->b.d_params + Lc.b,
                        a->b.d_params + a->std_off, d_inject_normal, c.seed_lo, c.seed_hi, (uint32_t)sample_counter, 0u, d_actions_out,
                        a->b.d_obs + tn * O, a->b.d_critic_obs + tn * P, a->b.d_actions + tn * A, a->b.d_values + tn, a->b.d_log_prob + tn,
-                       a->b.d_mu + tn * A, a->b.d_sigma + tn * A);
+                       a->b.d_mu + tn * A, a->b.d_sigma + tn * A, a->pend ? a->pend_args : ProcArgs{});
+    a->pend = false;
   } else {
+    ppo_flush_process(a, s);
     mlp_forward(a, a->actor, d_obs, N, a->w_ha, s);
     mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s2);
     ppo_join(a, s, s2);
@@ -1546,16 +1620,45 @@ int ppo_act_inference(PpoAlg* a, const float* d_obs, int32_t n, float* d_actions
   return 0;
 }
 
+static ProcArgs proc_args(PpoAlg* a, int32_t t, const float* d_rew, const uint8_t* d_dones, const uint8_t* d_time_outs) {
+  const PpoConfig& c = a->cfg;
+  const size_t tn = (size_t)t * c.num_envs;
+  ProcArgs p;
+  p.rew = d_rew; p.dones = d_dones; p.time_outs = d_time_outs; p.s_val = a->b.d_values + tn;
+  p.s_rew = a->b.d_rewards + tn; p.s_done = a->b.d_dones + tn;
+  p.ep_ret = a->b.d_ep_stats ? a->b.d_ep_return : nullptr; p.ep_len = a->b.d_ep_length; p.ep_stats = a->b.d_ep_stats;
+  const bool ring = a->b.d_ep_fin && a->b.d_ep_ring && a->b.d_ep_stats;      // then k_episode_ring also accumulates d_ep_stats
+  p.fin_ret = ring ? a->b.d_ep_fin + tn : nullptr;
+  p.fin_len = ring ? a->b.d_ep_fin + (size_t)c.num_steps * c.num_envs + tn : nullptr;
+  p.gamma = c.gamma;
+  return p;
+}
+// a deferred step that no k_act_heads picked up (end of the rollout, a non-fused head path, an immediate step behind it)
+static void ppo_flush_process(PpoAlg* a, hipStream_t s) {
+  if (!a->pend) return;
+  hipLaunchKernelGGL(k_process, dim3((a->cfg.num_envs + 255) / 256), dim3(256), 0, s, a->cfg.num_envs, a->pend_args);
+  a->pend = false;
+}
+
 int ppo_process_env_step(PpoAlg* a, int32_t t, const float* d_rew, const uint8_t* d_dones, const uint8_t* d_time_outs, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_process_env_step: buffers not bound"); return 1; }
   if (ppo_wrong_device(a)) return 1;
   const PpoConfig& c = a->cfg;
   if (t < 0 || t >= c.num_steps) { pf_set_error("ppo_process_env_step: transition index out of range"); return 1; }
-  size_t tn = (size_t)t * c.num_envs;
-  hipLaunchKernelGGL(k_process, dim3((c.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, c.num_envs, c.gamma, d_rew, d_dones,
-                     d_time_outs, a->b.d_values + tn, a->b.d_rewards + tn, a->b.d_dones + tn,
-                     a->b.d_ep_stats ? a->b.d_ep_return : nullptr, a->b.d_ep_length, a->b.d_ep_stats,
-                     a->b.d_ep_fin ? a->b.d_ep_fin + tn : nullptr, a->b.d_ep_fin ? a->b.d_ep_fin + (size_t)c.num_steps * c.num_envs + tn : nullptr);
+  ppo_flush_process(a, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_process, dim3((c.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, c.num_envs,
+                     proc_args(a, t, d_rew, d_dones, d_time_outs));
+  PPO_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ppo_process_env_step_deferred(PpoAlg* a, int32_t t, const float* d_rew, const uint8_t* d_dones, const uint8_t* d_time_outs, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_process_env_step_deferred: buffers not bound"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
+  if (t < 0 || t >= a->cfg.num_steps) { pf_set_error("ppo_process_env_step_deferred: transition index out of range"); return 1; }
+  ppo_flush_process(a, (hipStream_t)stream);
+  a->pend_args = proc_args(a, t, d_rew, d_dones, d_time_outs);
+  a->pend = true;
   PPO_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -1567,6 +1670,7 @@ int ppo_compute_returns(PpoAlg* a, const float* d_last_critic_obs, void* stream)
   hipStream_t s = (hipStream_t)stream;
   float* ws = a->b.d_workspace;
   const int N = c.num_envs, T = c.num_steps;
+  ppo_flush_process(a, s);
   split_weights(a, s);
   mlp_forward(a, a->critic, d_last_critic_obs, N, a->w_hc, s);
   PPO_HIP_OK(hipMemcpyAsync(ws + a->w_lastval, ws + a->w_hc[a->critic.nl - 1], sizeof(float) * N, hipMemcpyDeviceToDevice, s));
@@ -1576,7 +1680,13 @@ int ppo_compute_returns(PpoAlg* a, const float* d_last_critic_obs, void* stream)
   hipLaunchKernelGGL(k_moments1, dim3(RED_BLOCKS), dim3(256), 0, s, n, a->b.d_advantages, ws + a->w_partial);
   hipLaunchKernelGGL(k_moments2, dim3(1), dim3(64), 0, s, RED_BLOCKS, n, ws + a->w_partial, a->b.d_scalars);
   if (a->b.d_ep_ring && a->b.d_ep_fin && a->b.d_ep_stats)      // the runner's deque(maxlen=100) of finished episodes, on the device
-    hipLaunchKernelGGL(k_episode_ring, dim3(1), dim3(1024), 0, s, N, T, a->b.d_dones, a->b.d_ep_fin, a->b.d_ep_ring);
+  {
+    const long long chunk = ep_chunk_len((long long)n);
+    const int nchunks = (int)(((long long)n + chunk - 1) / chunk);
+    hipLaunchKernelGGL(k_episode_chunks, dim3(nchunks), dim3(256), 0, s, (long long)n, chunk, a->b.d_dones, a->b.d_ep_fin, ws + a->w_partial);
+    hipLaunchKernelGGL(k_episode_ring, dim3(1), dim3(1024), 0, s, N, T, chunk, nchunks, a->b.d_dones, a->b.d_ep_fin, ws + a->w_partial,
+                       a->b.d_ep_ring, a->b.d_ep_stats);
+  }
   PPO_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -604,24 +604,45 @@ struct PfKernel {
       const int blk = (i >= PF_ACT_W_HH0 && i < PF_ACT_W_HH0 + 256) ? PF_ACT_W_HH0 : (i >= PF_ACT_W_IH1 && i < PF_ACT_W_IH1 + 256) ? PF_ACT_W_IH1
                     : (i >= PF_ACT_W_HH1 && i < PF_ACT_W_HH1 + 256) ? PF_ACT_W_HH1 : -1;
       if (blk >= 0) { const int r = i - blk; o = act_w(blk, r >> 3, r & 7); }
+      if (i >= PF_ACT_W_IH0 && i < PF_ACT_W_IH0 + 64) { const int r = i - PF_ACT_W_IH0; o = act_w(PF_ACT_W_IH0, r >> 1, r & 1); }      // 32 x 2, same rule
       dst[o] = src[i];
     }
+  }
+  // The actuator state inside the LDS record: joint j's 32 floats [layer][h(8) c(8)] are rotated by 8 j (rec_slot below, applied by
+  // the record load / store), so the (joint, unit) lanes of the unit phase -- four joints per 32 lanes, all at the same offset of
+  // their block -- fall on 32 different banks instead of 8 (a 4-way conflict on every state read and write, and a 12-way one in the
+  // old per-joint output phase: ~150 of the ~190 conflict cycles per actuator call, profiles/r4_step_kernel_pmc.md).  Global
+  // memory keeps the plain [joint][layer][h c] order.
+  #ifndef PF_ACT_ROT
+#define PF_ACT_ROT 0
+#endif
+#ifndef PF_ACT_DPPLIN
+#define PF_ACT_DPPLIN 1
+#endif
+  PF_DEV int act_st(int j, int k8) { return LC::lstm_state + 32 * j + (PF_ACT_ROT ? ((k8 + 8 * j) & 31) : k8); }      // k8: 0 h0, 8 c0, 16 h1, 24 c1
+  PF_DEV int rec_slot(int i) {
+    if constexpr (LR) {
+      const int r = i - LC::lstm_state;
+      if (PF_ACT_ROT && (unsigned)r < (unsigned)(32 * ND)) return LC::lstm_state + (r & ~31) + ((r + ((r >> 5) << 3)) & 31);
+    }
+    return i;
   }
   PF_DEV void actuator_torques(Shared& sh, const float* P, const PfConfig& c) {
     float* S = sh.rec;
     for (int layer = 0; layer < 2; ++layer) {
       PF_LANES(e, ND * 32) {
         int j = e >> 5, g = e & 31;
-        float* st = S + LC::lstm_state + j * 32;          // [layer][h(8) c(8)]
+        const float* h0 = S + act_st(j, 0);
         float acc;
         if (layer == 0) {
           float x0 = ((S[LC::actions + j] * c.action_scale + c.default_dof_pos[j]) - S[LC::dof_pos + j]) * P[PF_ACT_IN_SCALE];
           float x1 = S[LC::dof_vel + j] * P[PF_ACT_IN_SCALE + 1];
-          acc = P[PF_ACT_B_IH0 + g] + P[PF_ACT_B_HH0 + g] + P[PF_ACT_W_IH0 + 2 * g] * x0 + P[PF_ACT_W_IH0 + 2 * g + 1] * x1;
-          for (int t = 0; t < 8; ++t) acc += P[act_w(PF_ACT_W_HH0, g, t)] * st[t];
+          acc = P[PF_ACT_B_IH0 + g] + P[PF_ACT_B_HH0 + g] + P[act_w(PF_ACT_W_IH0, g, 0)] * x0 + P[act_w(PF_ACT_W_IH0, g, 1)] * x1;
+          for (int t = 0; t < 8; ++t) acc += P[act_w(PF_ACT_W_HH0, g, t)] * h0[t];
         } else {
+          const float* h1 = S + act_st(j, 16);
           acc = P[PF_ACT_B_IH1 + g] + P[PF_ACT_B_HH1 + g];
-          for (int t = 0; t < 8; ++t) acc += P[act_w(PF_ACT_W_IH1, g, t)] * st[t] + P[act_w(PF_ACT_W_HH1, g, t)] * st[16 + t];
+          for (int t = 0; t < 8; ++t) acc += P[act_w(PF_ACT_W_IH1, g, t)] * h0[t] + P[act_w(PF_ACT_W_HH1, g, t)] * h1[t];
         }
         sh.gates[(g >> 3) * GST + 8 * j + (g & 7)] = acc;
       }
@@ -629,21 +650,38 @@ struct PfKernel {
       PF_LANES(e, ND * 8) {
         int j = e >> 3, u = e & 7;
         const float* G = sh.gates + e;
-        float* st = S + LC::lstm_state + j * 32 + layer * 16;
+        float* hs = S + act_st(j, layer * 16);
+        float* cs = S + act_st(j, layer * 16 + 8);
         float ig = sigm(G[0]), fg = sigm(G[GST]), gg = tanh_(G[2 * GST]), og = sigm(G[3 * GST]);
-        float cn = fg * st[8 + u] + ig * gg;
-        st[8 + u] = cn;
-        st[u] = og * tanh_(cn);
+        float cn = fg * cs[u] + ig * gg;
+        cs[u] = cn;
+        const float hn = og * tanh_(cn);
+        hs[u] = hn;
+#if !defined(PF_HOST_EMU) && PF_ACT_DPPLIN
+        // Linear(8 -> 1) on the second layer's output while it is still in registers: the eight unit lanes of a joint are half a
+        // DPP row, three v_add_f32_dpp sum them (whole groups are active in both passes of the lane loop)
+        if (layer == 1) {
+          float y = P[PF_ACT_W_LIN + u] * hn;
+          y += pf_dpp<0xB1>(y);
+          y += pf_dpp<0x4E>(y);
+          y += pf_dpp<0x141>(y);
+          if (u == 0) S[LC::torques + j] = (P[PF_ACT_B_LIN] + y) * P[PF_ACT_OUT_SCALE];
+        }
+#endif
       }
       PF_SYNC();
     }
+#if defined(PF_HOST_EMU) || !PF_ACT_DPPLIN
     PF_LANES(j, ND) {
-      const float* h2 = S + LC::lstm_state + j * 32 + 16;
-      float y = P[PF_ACT_B_LIN];
-      for (int t = 0; t < 8; ++t) y += P[PF_ACT_W_LIN + t] * h2[t];
-      S[LC::torques + j] = y * P[PF_ACT_OUT_SCALE];
+      const float* h2 = S + act_st(j, 16);
+      // the device sum's shape: pairs, quads, halves
+      const float p01 = P[PF_ACT_W_LIN + 0] * h2[0] + P[PF_ACT_W_LIN + 1] * h2[1], p23 = P[PF_ACT_W_LIN + 2] * h2[2] + P[PF_ACT_W_LIN + 3] * h2[3];
+      const float p45 = P[PF_ACT_W_LIN + 4] * h2[4] + P[PF_ACT_W_LIN + 5] * h2[5], p67 = P[PF_ACT_W_LIN + 6] * h2[6] + P[PF_ACT_W_LIN + 7] * h2[7];
+      const float y = (p01 + p23) + (p45 + p67);
+      S[LC::torques + j] = (P[PF_ACT_B_LIN] + y) * P[PF_ACT_OUT_SCALE];
     }
     PF_SYNC();
+#endif
   }
 
   // ------------------------------------------------------------------ PD torques (:523-547)
@@ -1711,12 +1749,12 @@ struct PfKernel {
       }
     }
     // a step (mode 0) reads the read-write part only: everything behind LC::rw_floats is written before it is read
-    { const int nload = g.mode == 0 ? LC::rw_floats : L.rec_floats; PF_LANES(i, nload) S[i] = grow[i]; }
+    { const int nload = g.mode == 0 ? LC::rw_floats : L.rec_floats; PF_LANES(i, nload) S[rec_slot(i)] = grow[i]; }
     PF_SYNC();
     if (g.mode == 1) {
       reset_env(sh, m, c, L, B, inj, env, g.step_counter);
       PF_ONE { B.d_episode_length[env] = 0; B.d_reset[env] = 1; }
-      PF_LANES(i, LC::rec_used) grow[i] = S[i];
+      PF_LANES(i, LC::rec_used) grow[i] = S[rec_slot(i)];
       return;
     }
     if (g.mode == 2 || g.mode == 3) {      // compute_observations() (:123-129, :320-326): measured_heights are taken afresh (:213 / :324)
@@ -1809,7 +1847,7 @@ struct PfKernel {
     PF_STAMP(sh, 14);
     {
       float* grow2 = B.d_state + (size_t)env2 * L.rec_floats;
-      PF_LANES(i, LC::rec_used) grow2[i] = S[i];      // (the padding behind the last field is never written)
+      PF_LANES(i, LC::rec_used) grow2[i] = S[rec_slot(i)];      // (the padding behind the last field is never written)
     }
     PF_SYNC();
     PF_STAMP(sh, 15);

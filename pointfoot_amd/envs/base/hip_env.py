@@ -179,6 +179,9 @@ class HipEnv:
             torch.zeros(self.num_envs, self.num_actions, device=self.device, requires_grad=False))
         return obs, privileged_obs
 
+    # step() returns the env's own rew_buf / reset_buf / extras['time_outs'] tensors; only the next step() rewrites them
+    step_outputs_persist = True
+
     def step(self, actions):
         """reference :170-193 — one fused kernel launch."""
         a = actions.detach().to(device=self.device, dtype=torch.float32).contiguous()

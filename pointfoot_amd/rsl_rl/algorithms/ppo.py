@@ -51,6 +51,7 @@ class PPO:
         self._h = None
         self._sample_counter = 0
         self.inject_normal = None      # tests: (N, A) standard-normal draws replacing Philox
+        self.env_outputs_persist = False      # see process_env_step; OnPolicyRunner sets it from env.step_outputs_persist
 
     # ------------------------------------------------------------------------------------------------ setup
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
@@ -149,7 +150,10 @@ class PPO:
     def process_env_step(self, rewards, dones, infos):
         t = self.storage.next_slot()
         to = infos.get('time_outs', None) if isinstance(infos, dict) else None
-        _abi.check(self._lib.ppo_process_env_step(self._h, t, rewards.data_ptr(), dones.data_ptr(), _ptr(to), self._stream()), self._lib)
+        # env_outputs_persist (set by the runner for an env that says so): rewards / dones / time_outs are the env's own buffers, rewritten
+        # only by its next step -- the processing then rides in the next act()'s head kernel instead of a launch of its own
+        fn = self._lib.ppo_process_env_step_deferred if self.env_outputs_persist else self._lib.ppo_process_env_step
+        _abi.check(fn(self._h, t, rewards.data_ptr(), dones.data_ptr(), _ptr(to), self._stream()), self._lib)
         self.storage.step += 1
         self.transition.clear()
         self.actor_critic.reset(dones)

@@ -36,6 +36,9 @@ class OnPolicyRunner:
         actor_critic = ActorCritic(self.env.num_obs, num_critic_obs, self.env.num_actions, **policy_kwargs).to(self.device)
         alg_kwargs = {k: v for k, v in self.alg_cfg.items() if k != "init_member_classes"}
         self.alg = PPO(actor_critic, device=self.device, seed=int(train_cfg.get("seed", 1)), **alg_kwargs)
+        # an env whose step() hands out its own buffers (rew_buf / reset_buf / time_out_buf, rewritten by the next step only) lets
+        # process_env_step ride in the next act()'s head kernel (ppo_process_env_step_deferred); PF_PPO_DEFER_PROCESS=0: own launch
+        self.alg.env_outputs_persist = bool(getattr(env, "step_outputs_persist", False)) and os.environ.get("PF_PPO_DEFER_PROCESS", "1") == "1"
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
         self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs], [self.env.num_privileged_obs],

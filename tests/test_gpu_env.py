@@ -635,7 +635,7 @@ def _anymal_full_step_parity(name, sim, rs, n, steps, count_outliers=False):
         bad = np.abs(sim.obs[m][:, nprop:] - ref.obs[m][:, nprop:]) > 1e-4
         scan_flips += int(bad.sum())
         L = sim.L
-        np.testing.assert_allclose(sim.state[m][:, L.lstm_state:L.lstm_state + 384], ref.state[m][:, L.lstm_state:L.lstm_state + 384], atol=1e-4)
+        np.testing.assert_allclose(sim.state[m][:, L.lstm_state:L.lstm_state + 384], ref.state[m][:, L.lstm_state:L.lstm_state + 384], atol=1e-4, rtol=1e-4)
         np.testing.assert_allclose(sim.f("commands", 4)[m], ref.f("commands", 4)[m], atol=1e-5)
         np.testing.assert_allclose(sim.f("root", 13)[m], ref.f("root", 13)[m], atol=2e-4, rtol=1e-4)
         assert (sim.episode_length[m] == ref.episode_length[m]).all()

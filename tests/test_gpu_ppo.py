@@ -388,31 +388,34 @@ def test_update_under_collectives_without_the_paired_mode_keeps_the_blocking_pat
     assert alg2._lib.ppo_supports_parts(alg2._h) == 1 and alg2._grad_groups is not None
 
 
-def test_episode_ring_is_the_runners_deque_of_finished_episodes():
+@pytest.mark.parametrize("N,T", [(300, 6), (23000, 23)])      # the second: more than 512 x 1024 flags per rollout (1024-flag chunks)
+def test_episode_ring_is_the_runners_deque_of_finished_episodes(N, T):
     """rsl_rl v1.0.2 OnPolicyRunner.learn: cur_reward_sum += rewards; cur_episode_length += 1; for the envs done on this step,
     in env order, rewbuffer / lenbuffer (deque(maxlen=100)) get the finished episode's return / length (call site
     legged_gym/scripts/train.py:44).  The device-side ring (k_process + k_episode_ring, no host sync) must hold exactly that
     deque after scripted episode ends -- sparse steps, a step with more than 100 ends at once, several rollouts."""
     from collections import deque
     from pointfoot_amd import dp
-    N, T, O, P, A = 300, 6, 27, 148, 6
+    O, P, A = 27, 148, 6
     alg, ref = make(N, T, O, P, A, [64, 32], seed=4)
     gen = torch.Generator(device="cuda:0").manual_seed(9)
     rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
     cur_r, cur_l = np.zeros(N, np.float32), np.zeros(N, np.float32)
     rates = [0.0, 0.002, 0.05, 0.6, 0.01, 0.0, 0.3, 0.003]
     step = 0
-    for rollout in range(5):
+    totals = np.zeros(3)          # what the runner logs from: sum of finished returns, of their lengths, their count (PpoBuffers.d_ep_stats)
+    for rollout in range(5 if N < 1000 else 2):
         for t in range(T):
             obs, cobs = torch.randn(N, O, device="cuda:0", generator=gen), torch.randn(N, P, device="cuda:0", generator=gen)
             alg.act(obs, cobs)
             rew = torch.randn(N, device="cuda:0", generator=gen)
-            dones = torch.rand(N, device="cuda:0", generator=gen) < rates[step % len(rates)]
+            dones = torch.rand(N, device="cuda:0", generator=gen) < rates[step % len(rates)] * (1.0 if N < 1000 else 0.002)
             step += 1
             alg.process_env_step(rew, dones, {"time_outs": dones & (torch.rand(N, device="cuda:0", generator=gen) < 0.5)})
             cur_r += rew.cpu().numpy(); cur_l += 1
             ids = np.nonzero(dones.cpu().numpy())[0]
             rewbuffer.extend(cur_r[ids].tolist()); lenbuffer.extend(cur_l[ids].tolist())
+            totals += np.array([cur_r[ids].sum(), cur_l[ids].sum(), len(ids)], np.float64)
             cur_r[ids] = 0; cur_l[ids] = 0
         alg.compute_returns(torch.randn(N, P, device="cuda:0", generator=gen))
         alg.storage.clear()
@@ -420,7 +423,44 @@ def test_episode_ring_is_the_runners_deque_of_finished_episodes():
         assert lens == list(lenbuffer), f"rollout {rollout}: episode lengths differ from the deque"
         np.testing.assert_allclose(rets, list(rewbuffer), rtol=1e-5, atol=1e-5)
         assert int(alg.ep_ring[3]) == step and int(alg.ep_ring[1]) == len(rewbuffer)
+        np.testing.assert_allclose(alg.ep_stats[:3].cpu().numpy(), totals, rtol=1e-5, atol=1e-3)
     assert len(rewbuffer) == 100
+
+
+def test_deferred_process_env_step_is_the_immediate_one():
+    """ppo_process_env_step_deferred (the transition processing in the tail of the next act()'s head kernel, or flushed by
+    compute_returns) against ppo_process_env_step on the same scripted rollouts: stored rewards (with the time-out bootstrap), dones,
+    episode sums / lengths, the finished-episode ring and the GAE outputs are bit-identical.  The env outputs are persistent
+    buffers rewritten in place once per step, as HipEnv.step hands them out."""
+    N, T, O, P, A = 300, 6, 27, 148, 6
+    algs = [make(N, T, O, P, A, [64, 32], seed=4)[0] for _ in range(2)]
+    algs[1].env_outputs_persist = True
+    gen = torch.Generator(device="cuda:0").manual_seed(11)
+    bufs = [(torch.zeros(N, device="cuda:0"), torch.zeros(N, device="cuda:0", dtype=torch.bool), torch.zeros(N, device="cuda:0", dtype=torch.bool))
+            for _ in range(2)]
+    for rollout in range(3):
+        for t in range(T):
+            obs, cobs = torch.randn(N, O, device="cuda:0", generator=gen), torch.randn(N, P, device="cuda:0", generator=gen)
+            noise = torch.randn(N, A, device="cuda:0", generator=gen)
+            rew = torch.randn(N, device="cuda:0", generator=gen)
+            dones = torch.rand(N, device="cuda:0", generator=gen) < (0.5 if t == 2 else 0.03)
+            tos = dones & (torch.rand(N, device="cuda:0", generator=gen) < 0.5)
+            for alg, (b_rew, b_done, b_to) in zip(algs, bufs):
+                alg.inject_normal = noise
+                alg.act(obs, cobs)
+                b_rew.copy_(rew); b_done.copy_(dones); b_to.copy_(tos)       # "env.step": the buffers change only here
+                alg.process_env_step(b_rew, b_done, {"time_outs": b_to})
+        last = torch.randn(N, P, device="cuda:0", generator=gen)
+        for alg in algs:
+            alg.compute_returns(last)
+        a, b = algs
+        for name in ("rewards", "dones", "values", "returns", "advantages"):
+            assert torch.equal(getattr(a.storage, name), getattr(b.storage, name)), name
+        assert torch.equal(a.ep_ring, b.ep_ring) and torch.equal(a.ep_fin, b.ep_fin)
+        assert torch.equal(a.ep_stats, b.ep_stats)       # summed once per rollout by k_episode_ring, in a fixed order
+        for alg in algs:
+            alg.storage.clear()
+    assert int(algs[1].ep_ring[1]) == 100
 
 
 def test_fused_optimiser_step_matches_the_separate_calls(monkeypatch):
