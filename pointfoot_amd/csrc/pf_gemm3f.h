@@ -63,13 +63,19 @@ template <int BN, int BK> struct G3fGeom {
   static constexpr int SW = BN < 64 ? BN : 64;                 // write-out strip width (columns): 4 waves x 32 x (SW + 4) floats
   static constexpr int STRIPS = 4 * 32 * (SW + 4) * 4;
   static constexpr int LDS = 2 * STAGE > STRIPS ? 2 * STAGE : STRIPS;
-  static_assert(NPB % 4 == 0, "B pieces are dealt evenly to the four waves");
-  static constexpr int B_PW = NPB / 4, NP = A_PW + B_PW;
+  template <int NSTG> static constexpr int lds() { return NSTG * STAGE > STRIPS ? NSTG * STAGE : STRIPS; }
+  static constexpr int B_PW = (NPB + 3) / 4, NP = A_PW + B_PW;      // B pieces per wave (BN = 32: six pieces, the last wave has none)
   __device__ static __forceinline__ int a_swz(int r) { return (r / (256 / A_ROWB)) & (A_CH - 1); }
   __device__ static __forceinline__ int b_swz(int r) { return (r / (256 / B_ROWB)) & (B_CH - 1); }
 };
 
-template <int BN, int BK, int EPI>
+// wait until at most N of this wave's vector-memory operations (here: DMA pieces) are outstanding
+template <int N> __device__ __forceinline__ void g3f_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NSTG LDS stages: the DMA of k-slice t + NSTG - 1 is issued under the MFMAs of slice t.  Two stages (two workgroups per CU) for the
+// update's launches; four for the rollout's 4096-row launches, where there is ONE workgroup per CU and nothing else hides the
+// ~1 us a slice takes to land.
+template <int BN, int BK, int EPI, int NSTG = 2>
 __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid, const int nblk, unsigned char* smem) {
   using Ge = G3fGeom<BN, BK>;
   constexpr int BM = G3F_BM, TN = BN / 32;
@@ -111,6 +117,7 @@ __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid,
         if (!full) off = (k0 + a_k[i] < g.K) ? off : OOB;
         g3f_dma16(a_rs, off, st + (A_PW * wave + i) * 1024);
       } else {
+        if (Ge::NPB % 4 != 0 && wave * B_PW + i - A_PW >= Ge::NPB) return;      // (uniform: `wave` is scalar)
         unsigned off = b_off[i - A_PW] + 2u * (unsigned)k0;
         if (!full) off = (k0 + b_k[i - A_PW] < g.ldbp) ? off : OOB;
         g3f_dma16(b_rs, off, st + A_BYTES + (wave * B_PW + i - A_PW) * 1024);
@@ -129,9 +136,9 @@ __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid,
     // (a burst of them at the head of the slice keeps every wave of the CU in the load queue while the matrix pipes idle)
     auto slice = [&](int it, auto next_tag) {
       constexpr bool NEXT = decltype(next_tag)::value && (G3F_ABLATE & 4) == 0;
-      const int k0n = (it + 1) * BK, bufn = (it + 1) & 1;
+      const int k0n = (it + NSTG - 1) * BK, bufn = (it + NSTG - 1) % NSTG;
       const bool fulln = is_full(k0n);
-      const unsigned char* st = smem + ((G3F_ABLATE & 4) ? 0 : (it & 1)) * STAGE;
+      const unsigned char* st = smem + ((G3F_ABLATE & 4) ? 0 : (it % NSTG)) * STAGE;
       const unsigned char* Bs = st + A_BYTES;
       constexpr int G = (BK / 16) * TN;      // MFMA groups of a slice
 #pragma unroll
@@ -175,16 +182,28 @@ __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid,
         }
       }
     };
+    static_assert((NSTG - 2) * NP <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NSTG == 2 || Ge::NPB % 4 == 0, "counted waits need the same number of pieces in every wave");
 #pragma unroll
-    for (int i = 0; i < NP; ++i) piece(i, 0, 0, is_full(0));
-    for (int it = 0; it + 1 < nt; ++it) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of slice `it` have landed
-      __syncthreads();                                      // ... everybody's have; and everybody is done reading the other stage
+    for (int sl = 0; sl < NSTG - 1; ++sl)
+      if (sl < nt) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) piece(i, sl * BK, sl, is_full(sl * BK));
+      }
+    int it = 0;
+    for (; it + NSTG - 1 < nt; ++it) {
+      g3f_wait_vm<(NSTG - 2) * NP>();                       // this wave's pieces of slice `it` have landed (NSTG - 2 newer slices may be in flight)
+      __syncthreads();                                      // ... everybody's have; and everybody is done reading the stage that is refilled now
       slice(it, std::true_type{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    slice(nt - 1, std::false_type{});
+    for (; it < nt; ++it) {                                 // the last NSTG - 1 slices: nothing left to issue, fewer and fewer in flight
+      const int newer = nt - 1 - it;
+      if (NSTG > 3 && newer >= 2) g3f_wait_vm<(NSTG > 3 ? 2 : 0) * NP>();
+      else if (NSTG > 2 && newer == 1) g3f_wait_vm<(NSTG > 2 ? 1 : 0) * NP>();
+      else g3f_wait_vm<0>();
+      __syncthreads();
+      slice(it, std::false_type{});
+    }
     __syncthreads();            // every wave is done with the operand stages: LDS becomes the write-out staging area
     if constexpr ((G3F_ABLATE & 32) != 0) {
 #pragma unroll
@@ -258,17 +277,17 @@ __device__ __forceinline__ void pf_gemm3f_body(const GemmArgs& g, const int bid,
   }
 }
 
-template <int BN, int BK, int EPI>
-__global__ __launch_bounds__(256, 2) void pf_gemm3f_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[G3fGeom<BN, BK>::LDS];
-  pf_gemm3f_body<BN, BK, EPI>(g, (int)blockIdx.x, (int)gridDim.x, smem);
+template <int BN, int BK, int EPI, int NSTG = 2>
+__global__ __launch_bounds__(256, NSTG > 2 ? 1 : 2) void pf_gemm3f_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[G3fGeom<BN, BK>::template lds<NSTG>()];
+  pf_gemm3f_body<BN, BK, EPI, NSTG>(g, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 // layer i of the actor and of the critic in one launch
-template <int BN, int BK, int EPI>
-__global__ __launch_bounds__(256, 2) void pf_gemm3f_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[G3fGeom<BN, BK>::LDS];
-  if ((int)blockIdx.x < nb0) pf_gemm3f_body<BN, BK, EPI>(g0, (int)blockIdx.x, nb0, smem);
-  else pf_gemm3f_body<BN, BK, EPI>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, smem);
+template <int BN, int BK, int EPI, int NSTG = 2>
+__global__ __launch_bounds__(256, NSTG > 2 ? 1 : 2) void pf_gemm3f_kernel2(GemmArgs g0, GemmArgs g1, int nb0) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[G3fGeom<BN, BK>::template lds<NSTG>()];
+  if ((int)blockIdx.x < nb0) pf_gemm3f_body<BN, BK, EPI, NSTG>(g0, (int)blockIdx.x, nb0, smem);
+  else pf_gemm3f_body<BN, BK, EPI, NSTG>(g1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, smem);
 }
 
 // The DMA path moves whole 16-byte chunks and the write-out whole float4: rows of A, C (and H) 16-byte aligned, K and N
@@ -290,12 +309,24 @@ static inline bool pf_gemm3f_ok(const GemmArgs& g) {
 // block, but 21.5 vs 18.1 us on 4096 x 256 x 512: the first stage takes twice as long to land and one workgroup per CU hides nothing.)
 static inline int pf_gemm3f_pick(int N, long tiles128) { return ((N % 128 == 0 && tiles128 >= 512) || N > 512) ? 0 : 1; }
 static inline long pf_gemm3f_tiles128(const GemmArgs& g) { return (long)((g.M + 127) / 128) * ((g.N + 127) / 128); }
+// Variant 2: 32 columns per block, for launches whose 64-column tiling leaves HALF the CUs without a workgroup (the rollout's
+// 4096 x 128 x 256 layer pair: 128 workgroups; 10.5 -> 10.2 us in the bench, 9.5 -> 9.0 alone).  Not for the 256-workgroup layer
+// (4096 x 256 x 512: 19.9 -> 21.4 us with two thin workgroups per CU).  These launches are a chain of small latencies inside one
+// wavefront per SIMD -- barrier, fragment reads, split, MFMAs, write-out: removing any one ingredient saves 1-3 of the 17 us,
+// removing the in-loop DMA 0.9, an empty launch takes 4.7 (profiles/r4_rollout_gemm_ablation.txt) -- and neither a deeper pipeline
+// (four LDS stages, NSTG = 4: 21.5 us) nor a second workgroup per CU shortens the chain.  PF_GEMM3F_THIN=0: never.
+static inline bool pf_gemm3f_thin(int blocks64) {
+  if (blocks64 > 128) return false;
+  const char* e = getenv("PF_GEMM3F_THIN");      // (read per launch: tests switch it)
+  return !(e && atoi(e) == 0);
+}
 template <int BN>
 static inline int pf_gemm3f_blocks(const GemmArgs& g) { return (((g.N + BN - 1) / BN) * ((g.M + G3F_BM - 1) / G3F_BM) + 7) / 8 * 8; }
 template <int EPI>
 static inline void pf_gemm3f_launch(const GemmArgs& g, hipStream_t s, int variant = -1) {
   if (variant < 0) variant = pf_gemm3f_pick(g.N, pf_gemm3f_tiles128(g));
   if (variant == 0) hipLaunchKernelGGL((pf_gemm3f_kernel<128, 32, EPI>), dim3(pf_gemm3f_blocks<128>(g)), dim3(256), 0, s, g);
+  else if (variant == 2 || (variant == 1 && pf_gemm3f_thin(pf_gemm3f_blocks<64>(g)))) hipLaunchKernelGGL((pf_gemm3f_kernel<32, 32, EPI>), dim3(pf_gemm3f_blocks<32>(g)), dim3(256), 0, s, g);
   else hipLaunchKernelGGL((pf_gemm3f_kernel<64, 32, EPI>), dim3(pf_gemm3f_blocks<64>(g)), dim3(256), 0, s, g);
 }
 template <int EPI>
@@ -303,7 +334,12 @@ static inline void pf_gemm3f_launch2(const GemmArgs& g0, const GemmArgs& g1, hip
   if (variant < 0) variant = pf_gemm3f_pick(g0.N < g1.N ? g0.N : g1.N, pf_gemm3f_tiles128(g0) + pf_gemm3f_tiles128(g1));
   if (variant == 1) {
     const int nb0 = pf_gemm3f_blocks<64>(g0), nb1 = pf_gemm3f_blocks<64>(g1);
-    hipLaunchKernelGGL((pf_gemm3f_kernel2<64, 32, EPI>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0);
+    if (pf_gemm3f_thin(nb0 + nb1)) variant = 2;
+    else { hipLaunchKernelGGL((pf_gemm3f_kernel2<64, 32, EPI>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0); return; }
+  }
+  if (variant == 2) {
+    const int nb0 = pf_gemm3f_blocks<32>(g0), nb1 = pf_gemm3f_blocks<32>(g1);
+    hipLaunchKernelGGL((pf_gemm3f_kernel2<32, 32, EPI>), dim3(nb0 + nb1), dim3(256), 0, s, g0, g1, nb0);
     return;
   }
   const int nb0 = pf_gemm3f_blocks<128>(g0), nb1 = pf_gemm3f_blocks<128>(g1);

@@ -178,16 +178,20 @@ def test_gemm_shapes_against_torch():
             torch.testing.assert_close(out, ref.actor(x), atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("path", ["fp32_mfma", "bf16x6", "bf16x6_planes", "bf16x6_dma"])
+@pytest.mark.parametrize("path", ["fp32_mfma", "bf16x6", "bf16x6_planes", "bf16x6_dma", "bf16x6_dma_nothin"])
 @pytest.mark.parametrize("mode", [0, 1, 2], ids=["fwd_bias_elu", "bwd_x_delu", "bwd_w_splitk_colsum"])
-def test_gemm_kernel_family_on_ragged_shapes(mode, path):
+def test_gemm_kernel_family_on_ragged_shapes(mode, path, monkeypatch):
     """Both GEMM families through the test hook -- the fp32 MFMA kernels (pf_gemm.h) and the fp32-by-exact-bf16-split
     kernels (pf_gemm3.h, "bf16x6") -- every tile variant, on shapes that exercise the edges: rows / columns / reduction
     lengths that are not multiples of the tile, of 4 (scalar loads and write-out) or of the k-slice, single-row
     problems, and split-K with a ragged last split.  Reference: FLOAT64 matmul; the tolerance is the float32 rounding
     budget of a length-K dot product and is THE SAME for both paths (the split drops only terms below 2^-23 |a b|)."""
-    if path in ("bf16x6_planes", "bf16x6_dma") and mode == 2:
+    if path in ("bf16x6_planes", "bf16x6_dma", "bf16x6_dma_nothin") and mode == 2:
         pytest.skip("the weight gradient has no pre-split operand (both operands are activations)")
+    # launches of at most 128 64-column workgroups (all of these shapes) are moved to the 32-column instance of the LDS-DMA kernel
+    # -- the rollout's last hidden layer; "_nothin" switches that off, so that tile 1 / -1 reach the 64-column instance too
+    monkeypatch.setenv("PF_GEMM3F_THIN", "0" if path.endswith("_nothin") else "1")
+    path = path.replace("_nothin", "")
     lib = common._abi.load()
     lib.pf_gemm_test.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
     dev = "cuda:0"
@@ -202,7 +206,7 @@ def test_gemm_kernel_family_on_ragged_shapes(mode, path):
     base = {"fp32_mfma": 0, "bf16x6": 10, "bf16x6_planes": 20, "bf16x6_dma": 30}[path]
     worst = 0.0
     for (M, N, K) in shapes:
-        for tile in ((0, 1, 2, -1) if path == "fp32_mfma" else (0, 1, -1) if path == "bf16x6_dma" else (0, 1, 2, 3, -1)):
+        for tile in ((0, 1, 2, -1) if path == "fp32_mfma" else (0, 1, 2, -1) if path == "bf16x6_dma" else (0, 1, 2, 3, -1)):
             for splits in ((1, 7, 64) if mode == 2 else (0,)):
                 if mode == 0: A, B = R(M, K), R(N, K)
                 elif mode == 1: A, B = R(M, K), R(K, N)
