@@ -1037,6 +1037,7 @@ struct PpoAlg {
   bool dma = true;         // bf16x6 forward / data-gradient GEMMs on the LDS-DMA kernel (pf_gemm3f.h) where shapes allow
   bool split3 = true;      // dense layers on the bf16 matrix pipes by exact three-way operand split (pf_gemm3.h); false: fp32 MFMA
   int max_rows = 0, max_width = 0, splits = 0;
+  bool l0_fp32 = false;    // rollout-sized launches (M <= 8192) of the input layers on the fp32 MFMA kernels (PF_PPO_L0_FP32=1: diagnostic)
   bool pend = false;       // a deferred process_env_step waits for the next ppo_act / ppo_compute_returns
   ProcArgs pend_args{};
 };
@@ -1296,7 +1297,8 @@ static void mlp_forward_pair(PpoAlg* a, const float* Xa, const float* Xc, int M,
     use_planes(a, ga, 0, i, false); use_planes(a, gc, 1, i, false);
     if (i == 0 && ldxa > 0) pad_input(ga, ldxa);
     if (i == 0 && ldxc > 0) pad_input(gc, ldxc);
-    if (a->split3 && a->dma && pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(gc) && pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(ga)) pf_gemm3f_launch2<GEMM_EPI_BIAS_ELU>(gc, ga, s);
+    if (i == 0 && a->l0_fp32 && M <= 8192) { ga.Bp = gc.Bp = nullptr; pf_gemm_auto2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s); }
+    else if (a->split3 && a->dma && pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(gc) && pf_gemm3f_ok<GEMM_EPI_BIAS_ELU>(ga)) pf_gemm3f_launch2<GEMM_EPI_BIAS_ELU>(gc, ga, s);
     else if (a->split3) pf_gemm3_launch2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);
     else pf_gemm_auto2<true, true, GEMM_EPI_BIAS_ELU>(gc, 0, ga, 0, s);     // the larger problem (critic) first
     ina = ws + a->w_ha[i]; inc = ws + a->w_hc[i];
@@ -1529,6 +1531,7 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
   if (const char* dm = getenv("PF_PPO_DMA")) a->dma = atoi(dm) != 0;           // diagnostics: 0 = register-staged bf16x6 kernels everywhere
   if (const char* fh = getenv("PF_PPO_FUSED_HEADS")) a->fused_heads = atoi(fh) != 0;
   if (const char* pr = getenv("PF_PPO_PAIRED")) a->paired = atoi(pr) != 0;
+  if (const char* l0 = getenv("PF_PPO_L0_FP32")) a->l0_fp32 = atoi(l0) != 0;
   a->paired = a->paired && a->fused_heads && a->actor.nl == a->critic.nl;
   const char* e = getenv("PF_PPO_DUAL_STREAM");
   a->dual = (e ? atoi(e) != 0 : true) && !a->paired;      // the second stream is only used by the unpaired path
