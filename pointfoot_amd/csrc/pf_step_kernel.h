@@ -23,6 +23,9 @@
 #ifndef PF_DUAL_INERTIA
 #define PF_DUAL_INERTIA 0  /* DUAL instances: 1 = the partner wavefront builds the body inertias and their composites, 0 = the dynamics side */
 #endif
+#ifndef PF_DUAL_SHARED_FK
+#define PF_DUAL_SHARED_FK 1  /* DUAL instances: 1 = the contact wavefront waits for the dynamics side's body frames of the substep, 0 = it walks the chains itself (own copy, same bits) */
+#endif
 #ifndef PF_DUAL_CREG
 #define PF_DUAL_CREG 4     /* DUAL instances: contact rows / joint-limit rows the PGS sweep keeps in registers (128 VGPRs) */
 #endif
@@ -426,7 +429,7 @@ struct PfKernel {
     typename std::conditional<DUAL, ScratchP, ScratchU>::type u;
     struct KinB { float Rw[NBD][9], r[NBD][3], ax[NBD][3]; };
     struct None {};
-    typename std::conditional<DUAL, KinB, None>::type kb;      // the contact wavefront's own body frames (same arithmetic, same bits)
+    typename std::conditional<DUAL && PF_DUAL_SHARED_FK == 0, KinB, None>::type kb;      // the contact wavefront's own body frames (same arithmetic, same bits)
     int ncon_x, anchor_x[2], flag_x; float hsum_x;             // handed from one wavefront to the other (DUAL)
     float park_x[4];                                           // values of the step parked across the substep loop (DUAL: 128 VGPRs)
     float dinv[NV];
@@ -984,6 +987,7 @@ struct PfKernel {
   PF_DEV void substep_dyn(Shared& sh, const ModelS& m, const PfConfig& c, const PfLayout& L, const PfBuffers& B, bool apply_ext, int env, float (&Lr)[NLT], float (&dv)[NDV], int handoff = 0) {
     float* S = sh.rec;
     kinematics<true>(sh, m, c, L);
+    if constexpr (DUAL && PF_DUAL_SHARED_FK != 0) PF_XSYNC();      // the body frames of this substep are in place: the partner starts its contact side
     PF_STAMP(sh, 1);
     // ---- per-body spatial inertia about O and bias wrench
     // (DUAL: inertias and their composites are position-only -- the partner wavefront builds them, run(), and flags them)
@@ -1722,9 +1726,9 @@ struct PfKernel {
       if (role == 1) {      // the contact wavefront: per substep, between the two meetings with its partner
         PF_SYNC();          // (its own copy of the model image is in place)
         for (int sub = 0; sub < c.decimation; ++sub) {
-          PF_XSYNC();       // the record holds this substep's state (and, the first time, the step's anchor cell)
+          PF_XSYNC();       // the record holds this substep's state (and, the first time, the step's anchor cell) [SHARED_FK: and the body frames]
           const int ix0 = sh.anchor_x[0], iy0 = sh.anchor_x[1];
-          kinematics<false, true>(sh, m, c, L);
+          if constexpr (PF_DUAL_SHARED_FK == 0) kinematics<false, true>(sh, m, c, L);
           // the bodies' spatial inertias and their composites depend on positions only, and this wavefront has time to spare:
           // it builds them on its own frames and flags them (the dynamics side picks them up after its velocity pass)
           if constexpr (PF_DUAL_INERTIA != 0) {
@@ -1733,7 +1737,7 @@ struct PfKernel {
             composite_inertias(sh, m);
             PF_HANDOFF_SET(sh.flag_x, sub + 1);
           }
-          const int nc = substep_contacts<true>(sh, m, c, L, B, env, sub, ix0, iy0);
+          const int nc = substep_contacts<PF_DUAL_SHARED_FK == 0>(sh, m, c, L, B, env, sub, ix0, iy0);
           PF_ONE { sh.ncon_x = nc; }
           PF_XSYNC();       // rows, targets and the contact count are handed over
         }
@@ -1795,7 +1799,7 @@ struct PfKernel {
       PF_SYNC();
       for (int sub = 0; sub < c.decimation; ++sub) {     // :180-185
         PF_STAMP(sh, 0);
-        if constexpr (DUAL) PF_XSYNC();      // the partner starts this substep's contact side
+        if constexpr (DUAL && PF_DUAL_SHARED_FK == 0) PF_XSYNC();      // the partner starts this substep's contact side (SHARED_FK: behind the kinematics, substep_dyn)
         bool pd = true;
         if constexpr (LR) { if (c.use_actuator_net && B.d_actuator_params) { actuator_torques(sh, ro.act, c); pd = false; } }
         if (pd) torques(sh, c, L, S + LC::dof_pos, 1, LC::dof_vel - LC::dof_pos);
