@@ -557,7 +557,7 @@ def main():
                          "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": step_ms, "bytes_per_launch": bytes_per_env * a.num_envs,
-                         "note": "latency/occupancy-bound by construction (SURVEY §8d honesty note); launch_ms from HIP events on the launch stream"},
+                         "note": "VALU-issue- and latency-bound, not HBM-bound (SURVEY §8d honesty note; DESIGN §4.1); launch_ms from HIP events around every 8th launch, on the launch stream"},
             "roofline_ppo": {"kernel": gemm_name + " inside the PPO update", "bound": "mfma", "achieved": ach_tf,
                              "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / MFMA_F32_PEAK_TFLOPS,
                              "update_ms": upd_ms, "flop_per_update": upd_flop,
