@@ -1037,6 +1037,7 @@ struct PpoAlg {
   bool dma = true;         // bf16x6 forward / data-gradient GEMMs on the LDS-DMA kernel (pf_gemm3f.h) where shapes allow
   bool split3 = true;      // dense layers on the bf16 matrix pipes by exact three-way operand split (pf_gemm3.h); false: fp32 MFMA
   int max_rows = 0, max_width = 0, splits = 0;
+  bool pair_rollout = true;   // ppo_act: actor and critic layer i in one launch (false: two chains on two streams; PF_PPO_PAIRED_ROLLOUT=0, diagnostic)
   bool l0_fp32 = false;    // rollout-sized launches (M <= 8192) of the input layers on the fp32 MFMA kernels (PF_PPO_L0_FP32=1: diagnostic)
   bool pend = false;       // a deferred process_env_step waits for the next ppo_act / ppo_compute_returns
   ProcArgs pend_args{};
@@ -1532,9 +1533,10 @@ PpoAlg* ppo_create(const PpoConfig* cfg, int32_t device) {
   if (const char* fh = getenv("PF_PPO_FUSED_HEADS")) a->fused_heads = atoi(fh) != 0;
   if (const char* pr = getenv("PF_PPO_PAIRED")) a->paired = atoi(pr) != 0;
   if (const char* l0 = getenv("PF_PPO_L0_FP32")) a->l0_fp32 = atoi(l0) != 0;
+  if (const char* pr = getenv("PF_PPO_PAIRED_ROLLOUT")) a->pair_rollout = atoi(pr) != 0;
   a->paired = a->paired && a->fused_heads && a->actor.nl == a->critic.nl;
   const char* e = getenv("PF_PPO_DUAL_STREAM");
-  a->dual = (e ? atoi(e) != 0 : true) && !a->paired;      // the second stream is only used by the unpaired path
+  a->dual = (e ? atoi(e) != 0 : true) && (!a->paired || !a->pair_rollout);      // the second stream is only used by the unpaired paths
   if (a->dual) {
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1579,10 +1581,11 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   // rollout also invalidates the permuted copy of the storage.
   if (t == 0 || !a->planes_valid) split_weights(a, s);
   if (t == 0) a->permuted = false;
-  hipStream_t s2 = a->paired ? s : ppo_fork(a, s);
+  const bool pair = a->paired && a->pair_rollout;
+  hipStream_t s2 = pair ? s : ppo_fork(a, s);
   size_t tn = (size_t)t * N;
   if (a->fused_heads) {
-    if (a->paired) mlp_forward_pair(a, d_obs, d_critic_obs, N, s);
+    if (pair) mlp_forward_pair(a, d_obs, d_critic_obs, N, s);
     else {
       mlp_forward(a, a->actor, d_obs, N, a->w_ha, s, false);
       mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s2, false);
