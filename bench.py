@@ -111,7 +111,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak
 STEP_BYTES_PER_ENV = 2072      # algorithmic bytes per env-step, pointfoot_rough
 PPO_MFLOP_PER_ENV_STEP = 13.4  # 0.84 rollout + 12.5 update
 # HBM bytes per step-kernel launch come from the committed rocprofv3 PMC summary of THIS kernel (tools/pmc_traffic.py
-# writes it from separate --pmc passes, with the guide's gfx950 corrections); used only when kernel, task and env count match.
+# writes it from separate --pmc passes: the L2's memory-side read / write requests by size -- the exact form of the guide's gfx950
+# doubling rule, profiles/r4_fetch_size_gather_calibration.txt); used only when kernel, task and env count match.
 TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", f) for f in
                     ("r4_step_kernel_hbm_pmc.json", "r4_step_kernel_hbm_pmc_anymal_c_rough.json")]      # profiles of the kernels as they are NOW
 # (older summaries -- r3_step_kernel_hbm_pmc*.json, r2_... -- describe kernels that no longer exist: single-wavefront PointFoot instance,

@@ -31,6 +31,11 @@ int pf_debug_set_stamps(PfEnv* env, unsigned* d_stamps);
  * record row): reads rows x row_floats floats once; tools/calib_fetch.py compares the counter with the known byte count. */
 int pf_debug_calib_read(const float* d_src, int rows, int row_floats, float* d_sink, void* stream);
 
+/* The same for the height scan's narrow gathers (three int16 samples per scan point, 121 points per robot, one point per lane):
+ * `robots` 32-lane groups sample the 12 x 12 cells at base[2 r], base[2 r + 1] of an int16 field with `cols` columns;
+ * tools/calib_gather.py counts the 64-byte sectors / 128-byte lines they touch on the host and compares. */
+int pf_debug_calib_gather(const int16_t* d_field, int cols, const int* d_base, int robots, float* d_sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,7 +56,30 @@ __global__ void pf_calib_read_kernel(const float* __restrict__ src, int rows, in
   if (acc == 1234.5678f) sink[0] = acc;      // keeps the loads alive without a store stream
 }
 
+// development hook: the height scan's gather pattern (_get_heights: 11 x 11 points, three int16 samples per point -- the cell's low
+// corner, its +x and its +y neighbour -- one point per lane of a 32-lane group) on a field of known size at host-chosen base cells,
+// so that the 64-byte sectors / 128-byte lines a launch touches are known exactly (tools/calib_gather.py)
+__global__ void pf_calib_gather_kernel(const int16_t* __restrict__ field, int cols, const int* __restrict__ base, int robots, float* __restrict__ sink) {
+  const int r = (int)blockIdx.x * 2 + ((int)threadIdx.x >> 5), lane = (int)threadIdx.x & 31;
+  if (r >= robots) return;
+  const int bx = base[2 * r], by = base[2 * r + 1];
+  int acc = 0;
+  for (int p = lane; p < 121; p += 32) {
+    const int ix = p / 11, iy = p - 11 * ix;
+    const size_t at = (size_t)(bx + ix) * cols + (by + iy);
+    const int h0 = field[at], h1 = field[at + cols], h2 = field[at + 1];
+    acc += min(h0, min(h1, h2));
+  }
+  if (acc == 0x7fffffff) sink[0] = (float)acc;
+}
+
 extern "C" {
+
+int pf_debug_calib_gather(const int16_t* d_field, int cols, const int* d_base, int robots, float* d_sink, void* stream) {
+  hipLaunchKernelGGL(pf_calib_gather_kernel, dim3((robots + 1) / 2), dim3(64), 0, (hipStream_t)stream, d_field, cols, d_base, robots, d_sink);
+  PF_HIP_OK(hipGetLastError());
+  return 0;
+}
 
 int pf_debug_calib_read(const float* d_src, int rows, int row_floats, float* d_sink, void* stream) {
   hipLaunchKernelGGL(pf_calib_read_kernel, dim3((rows + 1) / 2), dim3(64), 0, (hipStream_t)stream, d_src, rows, row_floats, d_sink);
