@@ -139,23 +139,72 @@ __global__ __launch_bounds__(256) void k_act_heads(int N, int A, int O, int P, i
   extern __shared__ __attribute__((aligned(16))) float asm_[];
   float* sWa = asm_;               // [A][Ka]
   float* sWc = sWa + A * Ka;       // [Kc]
-  for (int i = threadIdx.x; i < A * Ka; i += 256) sWa[i] = Wa[i];
-  for (int i = threadIdx.x; i < Kc; i += 256) sWc[i] = Wc[i];
-  {
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x, gs = (size_t)gridDim.x * 256;
-    for (size_t j = g; j < (size_t)N * O; j += gs) s_obs[j] = obs[j];
-    for (size_t j = g; j < (size_t)N * P; j += gs) s_cobs[j] = cobs[j];
-  }
-  __syncthreads();
   const int lane8 = threadIdx.x & 7;
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
-  if (i >= N) return;                 // whole 8-lane groups leave together (shuffles below stay inside a group)
+  // Every global load of the kernel goes out before the first wait: the hidden rows of this lane's env (up to 128 columns per
+  // network in registers), the deferred process_env_step's inputs, the head weights for LDS and the transition copy's first
+  // pieces -- one memory round trip for the launch instead of three dependent ones (weights -> barrier -> rows; a load -> store
+  // pair per copy iteration).
+  const bool rows4 = ((Ka | Kc) & 3) == 0, pre = rows4 && Ka <= 128 && Kc <= 128 && i < N;
+  float4 xa[4], xc[4];
+  if (pre) {
+    const float4* xr = reinterpret_cast<const float4*>(Ha + (size_t)i * Ka);
+    const float4* cr = reinterpret_cast<const float4*>(Hc + (size_t)i * Kc);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xa[u] = (lane8 + 8 * u) < (Ka >> 2) ? xr[lane8 + 8 * u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      xc[u] = (lane8 + 8 * u) < (Kc >> 2) ? cr[lane8 + 8 * u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  }
   ProcIn pin{};
-  if (prev.rew && lane8 == 0) pin = process_load(prev, i);      // the previous transition's deferred process_env_step: loads now, rest at the end
+  if (prev.rew && lane8 == 0 && i < N) pin = process_load(prev, i);      // the previous transition's deferred process_env_step: loads now, rest at the end
+  for (int k = threadIdx.x; k < A * Ka; k += 256) sWa[k] = Wa[k];
+  for (int k = threadIdx.x; k < Kc; k += 256) sWc[k] = Wc[k];
+  {
+    // transition copy: 16 bytes per lane where the two arrays allow it, four pieces in flight per lane
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x, gs = (size_t)gridDim.x * 256;
+    const size_t no = (size_t)N * O, np_ = (size_t)N * P;
+    const bool v4 = ((no | np_) & 3) == 0 && ((reinterpret_cast<uintptr_t>(obs) | reinterpret_cast<uintptr_t>(cobs) |
+                                                reinterpret_cast<uintptr_t>(s_obs) | reinterpret_cast<uintptr_t>(s_cobs)) & 15) == 0;
+    if (v4) {
+      const float4 *o4 = reinterpret_cast<const float4*>(obs), *c4 = reinterpret_cast<const float4*>(cobs);
+      float4 *so4 = reinterpret_cast<float4*>(s_obs), *sc4 = reinterpret_cast<float4*>(s_cobs);
+      const size_t n1 = no >> 2, n2 = np_ >> 2;
+      for (size_t j = g; j < n1 + n2; j += 4 * gs) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const size_t q = j + u * gs; if (q < n1 + n2) v[u] = q < n1 ? o4[q] : c4[q - n1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const size_t q = j + u * gs; if (q < n1 + n2) { if (q < n1) so4[q] = v[u]; else sc4[q - n1] = v[u]; } }
+      }
+    } else {
+      for (size_t j = g; j < no; j += gs) s_obs[j] = obs[j];
+      for (size_t j = g; j < np_; j += gs) s_cobs[j] = cobs[j];
+    }
+  }
+  __syncthreads();
+  if (i >= N) return;                 // whole 8-lane groups leave together (shuffles below stay inside a group)
   float mu[16], val = 0.0f;
 #pragma unroll
   for (int o = 0; o < 16; ++o) mu[o] = 0.0f;
-  if (((Ka | Kc) & 3) == 0) {
+  if (pre) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k4 = lane8 + 8 * u;
+      if (k4 < (Ka >> 2)) {
+        const float4 x = xa[u];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) if (o < A) {
+          float4 w = *reinterpret_cast<const float4*>(&sWa[o * Ka + 4 * k4]);
+          mu[o] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+        }
+      }
+      if (k4 < (Kc >> 2)) {
+        const float4 x = xc[u], w = *reinterpret_cast<const float4*>(&sWc[4 * k4]);
+        val += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+      }
+    }
+  } else if (rows4) {
     const float4* xr = reinterpret_cast<const float4*>(Ha + (size_t)i * Ka);
     for (int k4 = lane8; k4 < (Ka >> 2); k4 += 8) {
       float4 x = xr[k4];
