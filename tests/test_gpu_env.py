@@ -733,3 +733,27 @@ def test_hip_anymal_rough_8192_properties():
     assert resets > 0
     assert np.isfinite(sim.state).all()
     hip.close(); hip2.close()
+
+
+@pytest.mark.gpu
+def test_calibration_hooks_read_what_the_host_says():
+    """include/pointfoot_hip_dev.h: pf_debug_calib_gather / pf_debug_calib_read, the FETCH_SIZE calibration kernels behind
+    tools/calib_gather.py and tools/calib_fetch.py.  Both keep their loads alive by comparing a sum with a value ordinary data cannot
+    produce and writing the sink only on a hit: the gather hook must run over in-range cells and leave the sink alone, the read hook
+    must hit when one lane's sum IS the sentinel (so it reads the floats the byte count assumes)."""
+    import torch
+    lib = common._abi.load()
+    lib.pf_debug_calib_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.pf_debug_calib_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    field = torch.full((64, 64), 1, dtype=torch.int16, device="cuda:0")
+    base = torch.tensor([[5, 7], [40, 50]], dtype=torch.int32, device="cuda:0")      # 50 + 11 < 64: inside the field
+    sink = torch.zeros(4, device="cuda:0")
+    assert lib.pf_debug_calib_gather(field.data_ptr(), 64, base.data_ptr(), 2, sink.data_ptr(), s) == 0, lib.pf_last_error()
+    torch.cuda.synchronize()
+    assert float(sink.abs().sum()) == 0.0
+    src = torch.zeros(64, 160, device="cuda:0")
+    src[3, 0] = 1234.5678          # lane 0 of row 3 sums to exactly the sentinel: the sink is written
+    assert lib.pf_debug_calib_read(src.data_ptr(), 64, 160, sink.data_ptr(), s) == 0, lib.pf_last_error()
+    torch.cuda.synchronize()
+    assert abs(float(sink[0]) - 1234.5678) < 1e-3

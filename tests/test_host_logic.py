@@ -167,3 +167,37 @@ def test_trimesh_conversion_makes_vertical_faces():
     np.testing.assert_allclose(v[:, :, 2], hf * 0.005, atol=1e-7)
     v0, _ = convert_heightfield_to_trimesh(hf, 0.1, 0.005, None)
     np.testing.assert_allclose(v0.reshape(8, 6, 3)[3, :, 0], 0.3, atol=1e-6)
+
+
+def test_pmc_traffic_sums_requests_by_size(tmp_path):
+    """tools/pmc_traffic.py: with the request-size passes the traffic is 128 B x RDREQ_128B + 64 B x RDREQ_64B + 32 B x RDREQ_32B read and
+    64 B x WRREQ_64B + 32 B x the other write requests (profiles/r4_fetch_size_gather_calibration.txt), the doubling-rule figure kept beside it."""
+    import csv, json, subprocess, sys
+    kern = "void pf_step_kernel<9, 6, 2>(void const*)"
+
+    def pass_dir(name, counters):
+        d = tmp_path / name / "x"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            for i in range(8):
+                for c, v in counters.items():
+                    w.writerow([i, kern, c, v])
+                w.writerow([i, "other_kernel()", next(iter(counters)), 1e9])
+        return str(tmp_path / name)
+    dirs = [pass_dir("f", {"FETCH_SIZE": 100.0}), pass_dir("w", {"WRITE_SIZE": 50.0}),
+            pass_dir("r1", {"TCC_EA0_RDREQ_128B_sum": 1000.0, "TCC_EA0_RDREQ_64B_sum": 600.0}),
+            pass_dir("r2", {"TCC_EA0_RDREQ_sum": 1600.0, "TCC_EA0_RDREQ_32B_sum": 0.0}),
+            pass_dir("r3", {"TCC_EA0_WRREQ_sum": 900.0, "TCC_EA0_WRREQ_64B_sum": 700.0})]
+    out = tmp_path / "t.json"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), dirs[0], dirs[1], "pf_step_kernel<9", "pointfoot_rough", "4096",
+                    str(out)] + dirs[2:], check=True, capture_output=True)
+    rec = json.load(open(out))
+    assert rec["read_bytes_per_launch"] == 128 * 1000 + 64 * 600 and rec["write_bytes_per_launch"] == 64 * 700 + 32 * 200
+    assert rec["traffic_bytes_per_launch"] == rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]
+    assert rec["traffic_doubling_rule_bytes_per_launch"] == (2 * 100.0 + 50.0) * 1024
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), dirs[0], dirs[1], "pf_step_kernel<9", "pointfoot_rough", "4096",
+                    str(out)], check=True, capture_output=True)        # without the request-size passes: the guide's doubling rule
+    assert json.load(open(out))["traffic_bytes_per_launch"] == (2 * 100.0 + 50.0) * 1024
