@@ -371,6 +371,15 @@ __device__ __forceinline__ void pf_gemm3_body(const GemmArgs& g, const int bid, 
 // ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block and every lane receives one column (k-contiguous).
 // Row stride BM + 32 elements: the four rows of a block fall into four different 16-bank groups (conflict-free reads).
 typedef short pf_s16x4 __attribute__((ext_vector_type(4)));
+// Diagnostic build only (-DG3_TN_STAMPS, tools/gemm_tn_stamps.py): lane 0 of wavefront 0 of every workgroup accumulates s_memtime deltas per
+// phase of the weight-gradient loop -- [0] first barrier of a slice, [1] staging (wait for the operand loads, split, plane stores),
+// [2] second barrier, [3] issue of the next slice's loads, [4] fragment reads + MFMAs, [5] prologue, [6] column sums + write-out, [7] slices
+#if defined(G3_TN_STAMPS)
+__device__ unsigned long long g3_tn_stamp_acc[8];
+#define G3_STAMP(id) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[id] += t_ - tl_; tl_ = t_; } } while (0)
+#else
+#define G3_STAMP(id) ((void)0)
+#endif
 template <int BM, int BN>
 __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bid, const int nblk, unsigned char* smem) {
   // dwordx4 loads need 16-byte aligned rows (a 27-wide observation matrix has none): decided per operand, uniform per launch
@@ -407,6 +416,9 @@ __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bi
   const int grp = lane >> 4, lq = (lane >> 2) & 3, lp = lane & 3;
   const int frow = 8 * (grp >> 1) + lq, fcol = 16 * (grp & 1) + 4 * lp;
 
+#if defined(G3_TN_STAMPS)
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int t = bid; t < tmax; t += nblk) {
     const int lt = (t & 7) * per_xcd + (t >> 3);
     if (lt >= ntiles) continue;
@@ -462,11 +474,19 @@ __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bi
       return __builtin_bit_cast(pf_bf16x8, v);
     };
     fetch(k_begin);
+    G3_STAMP(5);
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
       __syncthreads();
+      G3_STAMP(0);
       stage();
+#if defined(G3_TN_STAMPS)
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // (lgkmcnt 0: the plane stores have left the wave)
+#endif
+      G3_STAMP(1);
       __syncthreads();
+      G3_STAMP(2);
       if (k0 + BK < k_end) fetch(k0 + BK);
+      G3_STAMP(3);
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
         pf_bf16x8 a[TM][3], b[TN][3];
@@ -495,6 +515,10 @@ __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bi
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
           }
       }
+#if defined(G3_TN_STAMPS)
+      if (tid == 0) st_[7] += 1;
+#endif
+      G3_STAMP(4);
     }
     __syncthreads();
     {
@@ -517,7 +541,11 @@ __device__ __forceinline__ void pf_gemm3_tn_body(const GemmArgs& g, const int bi
       __syncthreads();
     }
     g3_writeout<BM, BN, GEMM_EPI_NONE, true>(g, C, acc, m0, n0, smem);
+    G3_STAMP(6);
   }
+#if defined(G3_TN_STAMPS)
+  if (tid == 0) for (int u = 0; u < 8; ++u) atomicAdd(&g3_tn_stamp_acc[u], st_[u]);
+#endif
 }
 template <int BM, int BN>
 constexpr size_t pf_gemm3_tn_lds() {

@@ -1463,6 +1463,15 @@ static void ppo_join(PpoAlg* a, hipStream_t s, hipStream_t other) {
 
 extern "C" {
 
+#if defined(G3_TN_STAMPS)
+/* diagnostic build only (tools/gemm_tn_stamps.py; not declared in any header): read and clear the weight-gradient kernel's phase counters */
+int pf_debug_gemm_tn_stamps(unsigned long long* out8) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g3_tn_stamp_acc), sizeof(z)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g3_tn_stamp_acc), z, sizeof(z)) != hipSuccess;
+}
+#endif
+
 /* Development / test hook (not part of the drop-in boundary: declared in include/pointfoot_hip_dev.h): run one GEMM of the PPO
  * kernel family.  mode 0: C[M,N] = A[M,K] B[N,K]^T + bias, ELU; 1: C[M,N] = A[M,K] B[K,N] * ELU'(H); 2: C[M,N] = A[K,M]^T B[K,N]
  * (split-K slabs into `ws`, then reduced into C with the column sums of A in C[M*N .. M*N+M)).  tile: -1 auto, 0/1/2. */
