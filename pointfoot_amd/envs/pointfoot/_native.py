@@ -63,8 +63,11 @@ def build_model(cfg):
         m.feet_body[f] = b
     # self-collision geometry (asset.self_collisions == 0 enables it: pointfoot_rough_config.py:107, point_foot.py:942).
     # Capsules = the two equal-radius end spheres a cylinder / limb box became (urdf.py), or a single sphere; pairs =
-    # capsules on different branches of the tree (PhysX never collides a parent with its child; links of one chain
-    # cannot reach each other within the joint limits and are left out).
+    # capsules on different branches of the tree.  PhysX never collides a parent with its child; pairs further apart on ONE
+    # chain (hip-shank, thigh-foot) and pairs with the base are a MODELLING LIMIT of this build, not a property of the robots:
+    # PF_P441A's joint limits keep a leg's own links apart, ANYmal's continuous joints (q_lo/q_hi = -+1e9 above) do not, so a
+    # leg folded through itself or into the trunk passes without a self-contact here where PhysX would stop it.  (The physics
+    # is parity-unpinned either way; anymal_c_flat is the only task affected and is not a BASELINE configuration.)
     # Among the LeggedRobot tasks anymal_c_flat asks for it (anymal_c_flat_config.py:42, applied at legged_robot.py:680): 12 capsules /
     # 54 pairs on a quadruped, the kernel instance built for them; config 5 (anymal_c_rough) switches it off (anymal_c_rough_config.py:77).
     caps, pairs = [], []
