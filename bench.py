@@ -338,6 +338,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.single_device:
         local = 0
+    ndev = torch.cuda.device_count()
+    if local >= ndev:      # e.g. --gpus 8 on a node with fewer GPUs: say so instead of a HIP "invalid device ordinal" from deep inside
+        sys.exit(f"bench.py: rank {rank} (LOCAL_RANK {local}) needs cuda:{local}, but this node shows {ndev} GPU(s); --gpus {a.gpus} "
+                 f"is one process per GPU of ONE node (--backend gloo --single_device rehearses N > 1 on one GPU)")
     # PF_DP_SINGLE_RANK_COLLECTIVES=1: a process group of ONE rank with every collective of the N>1 path issued anyway (dp.collectives_on):
     # the rehearsal of the multi-GPU code path through RCCL on a one-GPU box
     rehearse1 = world == 1 and os.environ.get("PF_DP_SINGLE_RANK_COLLECTIVES", "0") == "1"
