@@ -384,21 +384,29 @@ def main():
     EV_EVERY = 8
     step_no = [0]
 
-    def timed_step(actions):
-        step_no[0] += 1
-        if step_no[0] % EV_EVERY:
-            return orig_step(actions)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        out = orig_step(actions)
-        e.record()
-        ev_pairs.append((s, e))
-        return out
+    def timed(fn):
+        def wrapped(arg):
+            step_no[0] += 1
+            if step_no[0] % EV_EVERY:
+                return fn(arg)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(arg)
+            e.record()
+            ev_pairs.append((s, e))
+            return out
+        return wrapped
+
+    timed_step = timed(orig_step)
+    orig_step_policy = getattr(env, "step_policy", None)       # PF_FUSED_POLICY_STEP=1: the runner steps the env through this one
+    timed_step_policy = timed(orig_step_policy) if orig_step_policy else None
 
     it_marks = []           # events at the head of every timed iteration (+ one at the end): per-iteration durations -> medians
 
     def iteration(obs, cobs, record):
         env.step = timed_step if record else orig_step
+        if orig_step_policy:
+            env.step_policy = timed_step_policy if record else orig_step_policy
         if record:
             m = torch.cuda.Event(enable_timing=True)
             m.record()
@@ -464,6 +472,11 @@ def main():
     if rank == 0:
         print(f"[bench] timed region done: {a.steps} iterations in {dt:.3f} s = {value:.0f} env-steps/s", file=sys.stderr, flush=True)
     step_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_pairs]))            # one fused env-step launch
+    # the policy's tail inside the same launch (OnPolicyRunner.rollout: PF_FUSED_POLICY_STEP, default on): algorithmic bytes per env-step =
+    # last hidden rows of both networks + the observation rows read and written once + action / mean / sigma rows + value + log-prob
+    fused_step = os.environ.get("PF_FUSED_POLICY_STEP", "1") == "1" and hasattr(env, "step_policy")
+    ac_ = runner.alg.actor_critic
+    tail_bytes = 4 * (ac_.actor_dims[-2] + ac_.critic_dims[-2] + 2 * (env.num_obs + (env.num_privileged_obs or env.num_obs)) + 3 * env.num_actions + 2)
     upd_ms = float(np.mean([s.elapsed_time(e) for s, e in up_pairs]))
     # medians over the timed iterations, and the collection-only / learn-only rates.  Device-side durations (HIP
     # events on the launch stream): iteration i = mark i -> mark i+1, collection = mark i -> update start, learn = the update.
@@ -489,6 +502,8 @@ def main():
             with contextlib.redirect_stdout(sys.stderr):
                 runner2, _ = task_registry.make_alg_runner(env=env, name=a.task, args=args2, log_root=None)
             env.step = orig_step
+            if orig_step_policy:
+                env.step_policy = orig_step_policy
             o2, c2 = env.get_observations(), env.get_privileged_observations()
             c2 = c2 if c2 is not None else o2
             for _ in range(max(2, a.warmup // 2)):
@@ -562,6 +577,12 @@ def main():
                          "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": step_ms, "bytes_per_launch": bytes_per_env * a.num_envs,
+                         "policy_tail": ({"in_this_launch": True, "bytes_per_launch": tail_bytes * a.num_envs,
+                                          "achieved_with_tail": (bytes_per_env + tail_bytes) * a.num_envs / (step_ms * 1e-3) / 1e9,
+                                          "note": "the launch also carries the policy's heads, the sampling and RolloutStorage.add_transitions (pf_step_policy: "
+                                                  "last hidden rows read, observation rows copied, action / mean / sigma / value / log-prob stored), which used to be "
+                                                  "a launch of their own (k_act_heads, 12 us); `achieved` / `frac` count the env step's SURVEY 8d bytes only, and "
+                                                  "`traffic` was measured on the launch without the tail (pf_step)"} if fused_step else {"in_this_launch": False}),
                          "note": "VALU-issue- and latency-bound, not HBM-bound (SURVEY §8d honesty note; DESIGN §4.1); launch_ms from HIP events around every 8th launch, on the launch stream"},
             "roofline_ppo": {"kernel": gemm_name + " inside the PPO update", "bound": "mfma", "achieved": ach_tf,
                              "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / MFMA_F32_PEAK_TFLOPS,

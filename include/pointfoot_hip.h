@@ -259,10 +259,50 @@ typedef struct PfInject {
   const float* d_feet_pos;     /* (N, nfeet, 3) */
 } PfInject;
 
+/* The policy's last step handed to the env step (pf_step_policy): everything PPO.act does behind the last hidden layer --
+ * the two thin heads, Normal(mu, std).sample(), log-prob, RolloutStorage.add_transitions for transition t -- and the
+ * PPO.process_env_step of transition t - 1, carried out by the step kernel's own wavefronts before they read the action.
+ * Filled by ppo_act_hidden (never by hand); all pointers are device pointers that stay valid until the step has run. */
+typedef struct PfPolicyHeads {
+  const float* d_ha;           /* (N, ka) actor, last hidden activations */
+  const float* d_hc;           /* (N, kc) critic, last hidden activations */
+  const float* d_wa;           /* (A, ka) action-mean head */
+  const float* d_ba;           /* (A) */
+  const float* d_wc;           /* (kc) value head */
+  const float* d_bc;           /* (1) */
+  const float* d_std;          /* (A) action std parameter */
+  const float* d_inject_normal;/* (N, A) standard normal draws replacing Philox (parity tests), or NULL */
+  const float* d_obs;          /* (N, O) the observations the policy acted on: copied to storage row t */
+  const float* d_critic_obs;   /* (N, P) */
+  float* d_actions_out;        /* (N, A) sampled actions (unclipped), as ppo_act returns them */
+  float* s_obs;                /* storage rows of transition t */
+  float* s_critic_obs;
+  float* s_actions;
+  float* s_values;
+  float* s_log_prob;
+  float* s_mu;
+  float* s_sigma;
+  /* deferred PPO.process_env_step of transition t - 1 (p_rew == NULL: none pending) */
+  const float* p_rew;
+  const uint8_t* p_dones;
+  const uint8_t* p_time_outs;  /* NULL: no bootstrap on time-outs */
+  const float* p_values;       /* storage values of transition t - 1 */
+  float* p_s_rew;
+  float* p_s_done;
+  float* p_ep_ret;             /* runner bookkeeping (NULL: off) */
+  float* p_ep_len;
+  float* p_ep_stats;
+  float* p_fin_ret;
+  float* p_fin_len;
+  float p_gamma;
+  int32_t ka, kc, num_obs, num_critic_obs, num_actions;
+  uint32_t seed_lo, seed_hi, counter, env_base;
+} PfPolicyHeads;
+
 typedef struct PfEnv PfEnv;
 
 const char* pf_last_error(void);
-/* sizes[0..6] = sizeof PfModel, PfConfig, PfLayout, PfBuffers, PfInject, PpoConfig, PpoBuffers */
+/* sizes[0..7] = sizeof PfModel, PfConfig, PfLayout, PfBuffers, PfInject, PpoConfig, PpoBuffers, PfPolicyHeads */
 void pf_abi_sizes(int64_t* sizes, int32_t n);
 /* record layout for a model/config pair (pure host computation) */
 int pf_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out);
@@ -285,6 +325,12 @@ int pf_update_config(PfEnv* env, const PfConfig* cfg);
  * the increment of :205.  With inject != NULL && inject->d_root != NULL the physics substeps are
  * skipped and the injected sim state is used instead (Python-layer parity mode). */
 int pf_step(PfEnv* env, const float* d_actions, int64_t step_counter, const PfInject* inject, void* stream);
+
+/* pf_step with the policy's heads inside the same launch: replaces the pair  actions = alg.act(obs, critic_obs);
+ * env.step(actions)  of rsl_rl OnPolicyRunner.learn (call site legged_gym/scripts/train.py:44 -> point_foot.py:170) for a
+ * policy whose dense layers have already run (ppo_act_hidden).  One launch fewer per policy step; storage rows, sampled
+ * actions and the env step are bit-identical to ppo_act followed by pf_step.  heads->num_actions must equal the env's. */
+int pf_step_policy(PfEnv* env, const PfPolicyHeads* heads, int64_t step_counter, void* stream);
 
 /* replaces: reset_idx(arange(N)) of PointFoot.reset() (point_foot.py:137-139); the zero-action step of
  * :140-141 is a separate pf_step call made by the host. */
@@ -379,6 +425,12 @@ int64_t ppo_workspace_floats(const PpoConfig* cfg);
  * that runs a dense layer -- not between the transitions of one rollout after an external rewrite of d_params. */
 int ppo_act(PpoAlg* alg, int32_t t, const float* d_obs, const float* d_critic_obs, float* d_actions_out,
             int64_t sample_counter, const float* d_inject_normal, void* stream);
+/* PPO.act up to the last hidden layer (the dense launches only), for an env that finishes the step itself: fills `heads` for
+ * pf_step_policy, which then computes the heads, samples, stores transition t and carries out a pending deferred
+ * process_env_step.  Returns 2 (and fills nothing) when the handle cannot hand its heads over (head widths above 128 or not
+ * multiples of 4, heads not fused): the caller falls back to ppo_act + pf_step. */
+int ppo_act_hidden(PpoAlg* alg, int32_t t, const float* d_obs, const float* d_critic_obs, float* d_actions_out,
+                   int64_t sample_counter, const float* d_inject_normal, PfPolicyHeads* heads, void* stream);
 /* actor forward only (act_inference / get_inference_policy) */
 int ppo_act_inference(PpoAlg* alg, const float* d_obs, int32_t n, float* d_actions_out, void* stream);
 /* PPO.process_env_step: rewards += gamma * value * time_outs; store rewards / dones for step t */

@@ -115,6 +115,16 @@ class PfInject(C.Structure):
     _fields_ = [(n, vp) for n in ("d_rand", "d_dof_pre", "d_dof_post", "d_root", "d_contact", "d_feet_pos")]
 
 
+class PfPolicyHeads(C.Structure):
+    """include/pointfoot_hip.h PfPolicyHeads: filled by ppo_act_hidden, consumed by pf_step_policy."""
+    _fields_ = [(n, vp) for n in (
+        "d_ha", "d_hc", "d_wa", "d_ba", "d_wc", "d_bc", "d_std", "d_inject_normal", "d_obs", "d_critic_obs", "d_actions_out",
+        "s_obs", "s_critic_obs", "s_actions", "s_values", "s_log_prob", "s_mu", "s_sigma",
+        "p_rew", "p_dones", "p_time_outs", "p_values", "p_s_rew", "p_s_done", "p_ep_ret", "p_ep_len", "p_ep_stats", "p_fin_ret", "p_fin_len")] + [
+        ("p_gamma", f32), ("ka", i32), ("kc", i32), ("num_obs", i32), ("num_critic_obs", i32), ("num_actions", i32),
+        ("seed_lo", u32), ("seed_hi", u32), ("counter", u32), ("env_base", u32)]
+
+
 class PpoConfig(C.Structure):
     _fields_ = [
         ("num_envs", i32), ("num_steps", i32), ("num_obs", i32), ("num_critic_obs", i32), ("num_actions", i32),
@@ -160,9 +170,9 @@ def load():
     lib.pf_abi_sizes.argtypes = [C.POINTER(C.c_int64), i32]
     sizes = (C.c_int64 * 8)()
     lib.pf_abi_sizes(sizes, 8)
-    mine = [C.sizeof(t) for t in (PfModel, PfConfig, PfLayout, PfBuffers, PfInject, PpoConfig, PpoBuffers)]
-    if list(sizes[:7]) != mine:
-        raise RuntimeError(f"ABI mismatch between pointfoot_hip.h {list(sizes[:7])} and _abi.py {mine}")
+    mine = [C.sizeof(t) for t in (PfModel, PfConfig, PfLayout, PfBuffers, PfInject, PpoConfig, PpoBuffers, PfPolicyHeads)]
+    if list(sizes[:8]) != mine:
+        raise RuntimeError(f"ABI mismatch between pointfoot_hip.h {list(sizes[:8])} and _abi.py {mine}")
     lib.pf_layout.argtypes = [C.POINTER(PfModel), C.POINTER(PfConfig), C.POINTER(PfLayout)]
     lib.pf_layout.restype = i32
     lib.pf_create.argtypes = [C.POINTER(PfModel), C.POINTER(PfConfig), i32]
@@ -177,11 +187,13 @@ def load():
     lib.pf_set_reset_stats_next.argtypes = [vp, vp]
     lib.pf_set_reset_stats_next.restype = i32
     lib.pf_step.argtypes = [vp, vp, C.c_int64, C.POINTER(PfInject), vp]
+    lib.pf_step_policy.argtypes = [vp, C.POINTER(PfPolicyHeads), C.c_int64, vp]
+    lib.pf_step_policy.restype = i32
     lib.pf_reset_all.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_reset_idx.argtypes = [vp, vp, C.c_int64, C.POINTER(PfInject), vp]
     lib.pf_compute_observations.argtypes = [vp, C.c_int64, C.POINTER(PfInject), vp]
     _bind_ppo(lib)
-    for fn in ("pf_bind_buffers", "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations"):
+    for fn in ("pf_bind_buffers", "pf_update_config", "pf_step", "pf_step_policy", "pf_reset_all", "pf_reset_idx", "pf_compute_observations"):
         getattr(lib, fn).restype = i32
     _LIB = lib
     return lib
@@ -199,6 +211,8 @@ def _bind_ppo(lib):
     lib.ppo_workspace_floats.argtypes = [C.POINTER(PpoConfig)]
     lib.ppo_workspace_floats.restype = C.c_int64
     lib.ppo_act.argtypes = [vp, i32, vp, vp, vp, C.c_int64, vp, vp]
+    lib.ppo_act_hidden.argtypes = [vp, i32, vp, vp, vp, C.c_int64, vp, C.POINTER(PfPolicyHeads), vp]
+    lib.ppo_act_hidden.restype = i32
     lib.ppo_act_inference.argtypes = [vp, vp, i32, vp, vp]
     lib.ppo_process_env_step.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.ppo_process_env_step_deferred.argtypes = [vp, i32, vp, vp, vp, vp]
@@ -227,7 +241,7 @@ def check(rc, lib=None):
 
 EXPORTED_SYMBOLS = [
     "pf_last_error", "pf_abi_sizes", "pf_layout", "pf_create", "pf_destroy", "pf_bind_buffers", "pf_set_reset_stats", "pf_set_reset_stats_next", "pf_measure_heights",
-    "pf_update_config", "pf_step", "pf_reset_all", "pf_reset_idx", "pf_compute_observations",
-    "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act",
+    "pf_update_config", "pf_step", "pf_step_policy", "pf_reset_all", "pf_reset_idx", "pf_compute_observations",
+    "ppo_create", "ppo_destroy", "ppo_bind_buffers", "ppo_num_params", "ppo_param_offsets", "ppo_workspace_floats", "ppo_act", "ppo_act_hidden",
     "ppo_act_inference", "ppo_process_env_step", "ppo_process_env_step_deferred", "ppo_compute_returns", "ppo_normalize_advantages",
     "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_backward_part", "ppo_grad_groups", "ppo_supports_parts", "ppo_minibatch_apply", "ppo_minibatch_step"]

@@ -90,9 +90,9 @@ int pf_debug_calib_read(const float* d_src, int rows, int row_floats, float* d_s
 const char* pf_last_error(void) { return g_pf_error.c_str(); }
 
 void pf_abi_sizes(int64_t* sizes, int32_t n) {
-  const int64_t v[7] = {sizeof(PfModel), sizeof(PfConfig), sizeof(PfLayout), sizeof(PfBuffers), sizeof(PfInject),
-                        sizeof(PpoConfig), sizeof(PpoBuffers)};
-  for (int i = 0; i < n && i < 7; ++i) sizes[i] = v[i];
+  const int64_t v[8] = {sizeof(PfModel), sizeof(PfConfig), sizeof(PfLayout), sizeof(PfBuffers), sizeof(PfInject),
+                        sizeof(PpoConfig), sizeof(PpoBuffers), sizeof(PfPolicyHeads)};
+  for (int i = 0; i < n && i < 8; ++i) sizes[i] = v[i];
 }
 
 int pf_layout(const PfModel* model, const PfConfig* cfg, PfLayout* out) {
@@ -233,9 +233,10 @@ int pf_update_config(PfEnv* e, const PfConfig* cfg) {
   return 0;
 }
 
-static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, const PfInject* inject, void* stream, int mode, const uint8_t* d_mask = nullptr) {
+static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, const PfInject* inject, void* stream, int mode, const uint8_t* d_mask = nullptr,
+                     const PfPolicyHeads* heads = nullptr) {
   if (!e || !e->bound) { pf_set_error("pf_step: buffers not bound"); return 1; }
-  if (mode == 0 && !d_actions) { pf_set_error("pf_step: actions pointer is NULL"); return 1; }
+  if (mode == 0 && !d_actions && !heads) { pf_set_error("pf_step: actions pointer is NULL"); return 1; }
   { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != e->device) { pf_set_error("pf_step: the calling thread's current HIP device is not the env's device (torch.cuda.set_device)"); return 1; } }
   PfStepArgs g;
   g.packed = e->d_packed; g.cfg = e->d_cfg; g.L = e->layout; g.b = e->bufs;
@@ -244,6 +245,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
     pf_set_error("pf_step: incomplete injected sim state"); return 1;
   }
   g.actions = d_actions; g.step_counter = step_counter; g.mode = mode; g.stamps = e->d_stamps; g.reset_mask = d_mask;
+  if (heads) g.heads = *heads; else std::memset(&g.heads, 0, sizeof(g.heads));
   hipStream_t s = (hipStream_t)stream;
   g.stats_next = nullptr;
   if (e->bufs.d_reset_stats && mode < 2) {
@@ -272,6 +274,18 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
 
 int pf_step(PfEnv* e, const float* d_actions, int64_t step_counter, const PfInject* inject, void* stream) {
   return pf_launch(e, d_actions, step_counter, inject, stream, 0);
+}
+int pf_step_policy(PfEnv* e, const PfPolicyHeads* h, int64_t step_counter, void* stream) {
+  if (!h || !h->d_ha || !h->d_hc || !h->d_wa || !h->d_ba || !h->d_wc || !h->d_bc || !h->d_std || !h->d_obs || !h->d_critic_obs || !h->d_actions_out ||
+      !h->s_obs || !h->s_critic_obs || !h->s_actions || !h->s_values || !h->s_log_prob || !h->s_mu || !h->s_sigma) {
+    pf_set_error("pf_step_policy: incomplete PfPolicyHeads (fill it with ppo_act_hidden)"); return 1;
+  }
+  if (e && (h->num_actions != e->cfg.num_actions || h->num_actions > 16)) { pf_set_error("pf_step_policy: the policy's action count is not the env's"); return 1; }
+  if (h->ka < 4 || h->kc < 4 || h->ka > 128 || h->kc > 128 || ((h->ka | h->kc) & 3) || ((((size_t)h->d_ha) | ((size_t)h->d_hc) | ((size_t)h->d_wa) | ((size_t)h->d_wc)) & 15)) {
+    pf_set_error("pf_step_policy: head widths must be multiples of 4 up to 128 with 16-byte aligned rows"); return 1;
+  }
+  if (h->p_rew && !(h->p_dones && h->p_s_rew && h->p_s_done && (!h->p_time_outs || h->p_values))) { pf_set_error("pf_step_policy: incomplete deferred process_env_step"); return 1; }
+  return pf_launch(e, nullptr, step_counter, nullptr, stream, 0, nullptr, h);
 }
 int pf_reset_all(PfEnv* e, int64_t step_counter, const PfInject* inject, void* stream) {
   return pf_launch(e, nullptr, step_counter, inject, stream, 1);

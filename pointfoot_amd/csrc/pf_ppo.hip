@@ -1672,6 +1672,52 @@ int ppo_act(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs,
   return 0;
 }
 
+// PPO.act up to the last hidden layer; the heads, the sampling, the transition store and a pending deferred process_env_step are
+// handed to the env step (pf_step_policy) as a PfPolicyHeads -- exactly the arguments k_act_heads would have been launched with.
+int ppo_act_hidden(PpoAlg* a, int32_t t, const float* d_obs, const float* d_critic_obs, float* d_actions_out, int64_t sample_counter,
+                   const float* d_inject_normal, PfPolicyHeads* h, void* stream) {
+  if (!a || !a->bound) { pf_set_error("ppo_act_hidden: buffers not bound"); return 1; }
+  if (!h || !d_actions_out) { pf_set_error("ppo_act_hidden: null argument"); return 1; }
+  if (ppo_wrong_device(a)) return 1;
+  const PpoConfig& c = a->cfg;
+  if (t < 0 || t >= c.num_steps) { pf_set_error("ppo_act_hidden: transition index out of range (rollout buffer overflow)"); return 1; }
+  const Layer& La = a->actor.l[a->actor.nl - 1];
+  const Layer& Lc = a->critic.l[a->critic.nl - 1];
+  const int A = c.num_actions;
+  if (!a->fused_heads || A > 16 || La.in > 128 || Lc.in > 128 || ((La.in | Lc.in) & 3) || a->actor.nl < 2 || a->critic.nl < 2) return 2;
+  hipStream_t s = (hipStream_t)stream;
+  const int N = c.num_envs, O = c.num_obs, P = c.num_critic_obs;
+  float* ws = a->b.d_workspace;
+  if (t == 0 || !a->planes_valid) split_weights(a, s);
+  if (t == 0) a->permuted = false;
+  const bool pair = a->paired && a->pair_rollout;
+  if (pair) mlp_forward_pair(a, d_obs, d_critic_obs, N, s);
+  else {
+    hipStream_t s2 = ppo_fork(a, s);
+    mlp_forward(a, a->actor, d_obs, N, a->w_ha, s, false);
+    mlp_forward(a, a->critic, d_critic_obs, N, a->w_hc, s2, false);
+    ppo_join(a, s, s2);
+  }
+  PPO_HIP_OK(hipGetLastError());
+  const size_t tn = (size_t)t * N;
+  std::memset(h, 0, sizeof(*h));
+  h->d_ha = ws + a->w_ha[a->actor.nl - 2]; h->d_hc = ws + a->w_hc[a->critic.nl - 2];
+  h->d_wa = a->b.d_params + La.w; h->d_ba = a->b.d_params + La.b; h->d_wc = a->b.d_params + Lc.w; h->d_bc = a->b.d_params + Lc.b;
+  h->d_std = a->b.d_params + a->std_off; h->d_inject_normal = d_inject_normal;
+  h->d_obs = d_obs; h->d_critic_obs = d_critic_obs; h->d_actions_out = d_actions_out;
+  h->s_obs = a->b.d_obs + tn * O; h->s_critic_obs = a->b.d_critic_obs + tn * P; h->s_actions = a->b.d_actions + tn * A;
+  h->s_values = a->b.d_values + tn; h->s_log_prob = a->b.d_log_prob + tn; h->s_mu = a->b.d_mu + tn * A; h->s_sigma = a->b.d_sigma + tn * A;
+  if (a->pend) {
+    const ProcArgs& q = a->pend_args;
+    h->p_rew = q.rew; h->p_dones = q.dones; h->p_time_outs = q.time_outs; h->p_values = q.s_val; h->p_s_rew = q.s_rew; h->p_s_done = q.s_done;
+    h->p_ep_ret = q.ep_ret; h->p_ep_len = q.ep_len; h->p_ep_stats = q.ep_stats; h->p_fin_ret = q.fin_ret; h->p_fin_len = q.fin_len; h->p_gamma = q.gamma;
+    a->pend = false;      // carried out by the step launch the caller enqueues next on this stream
+  }
+  h->ka = La.in; h->kc = Lc.in; h->num_obs = O; h->num_critic_obs = P; h->num_actions = A;
+  h->seed_lo = c.seed_lo; h->seed_hi = c.seed_hi; h->counter = (uint32_t)sample_counter; h->env_base = 0u;
+  return 0;
+}
+
 int ppo_act_inference(PpoAlg* a, const float* d_obs, int32_t n, float* d_actions_out, void* stream) {
   if (!a || !a->bound) { pf_set_error("ppo_act_inference: buffers not bound"); return 1; }
   if (ppo_wrong_device(a)) return 1;

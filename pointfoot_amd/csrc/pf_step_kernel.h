@@ -188,6 +188,17 @@ PF_DEV float pf_philox_slot(uint32_t k0, uint32_t k1, uint32_t env, uint32_t ste
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
+// the four raw words (pf_ppo.hip philox4: the action sampler's counter layout is (env, sample counter, 1, action index))
+PF_DEV void pf_philox_raw(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* o) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
 // Diagnostic build only (-DPF_STAMPS, tools/step_stamps.py): lane 0 accumulates s_memtime deltas per phase into
 // args.stamps[env][PF_NSTAMP]; the real kernel contains no stamp.
 #define PF_NSTAMP 16
@@ -210,6 +221,7 @@ struct PfStepArgs {
   unsigned* stamps;       // diagnostic build only, else NULL
   float* stats_next;      // next step's statistics slot, cleared by this launch (NULL: the host clears slots itself)
   const uint8_t* reset_mask;   // mode 1 only: envs to reset (NULL: all) -- reset_idx(env_ids), point_foot.py:249
+  PfPolicyHeads heads;         // pf_step_policy: the policy's heads, sampling and transition store run here (d_ha == NULL: plain pf_step)
 };
 
 // KPR: self-collision capsule pairs the instance is built for (0: built without self-collision)
@@ -1702,6 +1714,106 @@ struct PfKernel {
   // ------------------------------------------------------------------ the whole step for env `env`
   // Every wavefront stages the workgroup's read-only block itself (same values from every wave: no cross-wave ordering is
   // needed, so PF_SYNC stays wave-local and robots of one workgroup may diverge freely).
+#if !defined(PF_HOST_EMU)
+  // pf_step_policy: what k_act_heads (pf_ppo.hip) does for one env, by the env's own lanes before they read the action --
+  // rsl_rl PPO.act behind the last hidden layer (both thin heads, Normal(mu, std).sample(), log-prob, RolloutStorage.add_transitions
+  // for transition t) and the deferred PPO.process_env_step of transition t - 1.  One launch fewer per policy step.
+  // SAME SUMS IN THE SAME ORDER as k_act_heads, so that both paths give the same bits: there, lane8 of an 8-lane group adds the
+  // products of the 16-byte chunks lane8, lane8 + 8, lane8 + 16, lane8 + 24 of the hidden row in that order and the eight partial
+  // sums meet in xor-1 / 2 / 4 butterflies; here lane l holds the product of chunk l and the same additions are made from shuffles.
+  PF_DEV void policy_heads(Shared& sh, const PfConfig& c, const PfPolicyHeads& h, int env) {
+    float* S = sh.rec;
+    const int lane = PF_LANE_ID, wl = (int)threadIdx.x & 63, hb = wl & ~(PF_W - 1), b = lane & 7;
+    constexpr int A = ND;      // pf_step_policy checks h.num_actions against the env's (== ND)
+    const int Ka = h.ka, Kc = h.kc, nca = Ka >> 2, ncc = Kc >> 2;
+    // every global load the sums need goes out first
+    float4 xa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), xc = xa, wc = xa;
+    if (lane < nca) xa = reinterpret_cast<const float4*>(h.d_ha + (size_t)env * Ka)[lane];
+    if (lane < ncc) { xc = reinterpret_cast<const float4*>(h.d_hc + (size_t)env * Kc)[lane]; wc = reinterpret_cast<const float4*>(h.d_wc)[lane]; }
+    float p[A], pv = 0.0f;
+#pragma unroll
+    for (int o = 0; o < A; ++o) {
+      p[o] = 0.0f;
+      if (lane < nca) {
+        const float4 w = reinterpret_cast<const float4*>(h.d_wa + (size_t)o * Ka)[lane];
+        p[o] = (xa.x * w.x + xa.y * w.y) + (xa.z * w.z + xa.w * w.w);
+      }
+    }
+    if (lane < ncc) pv = (xc.x * wc.x + xc.y * wc.y) + (xc.z * wc.z + xc.w * wc.w);
+    // the previous transition's deferred process_env_step: loads now, the rest at the end
+    const bool proc = h.p_rew != nullptr && lane == 0;
+    float pr = 0.0f, per = 0.0f, pel = 0.0f, pval = 0.0f; bool pdone = false, pto = false;
+    if (proc) {
+      pr = h.p_rew[env]; pdone = h.p_dones[env] != 0;
+      if (h.p_ep_ret) { per = h.p_ep_ret[env]; pel = h.p_ep_len[env]; }
+      if (h.p_time_outs) { pto = h.p_time_outs[env] != 0; pval = h.p_values[env]; }
+    }
+    // RolloutStorage.add_transitions: the observations the policy acted on (this env's rows)
+    { const int O = h.num_obs, P = h.num_critic_obs;
+      PF_LANES(i, O) h.s_obs[(size_t)env * O + i] = h.d_obs[(size_t)env * O + i];
+      PF_LANES(i, P) h.s_critic_obs[(size_t)env * P + i] = h.d_critic_obs[(size_t)env * P + i]; }
+    auto comb = [&](float q, int nch) {
+      float s0 = __shfl(q, hb + b, 64);
+      const float t1 = __shfl(q, hb + b + 8, 64), t2 = __shfl(q, hb + b + 16, 64), t3 = __shfl(q, hb + b + 24, 64);
+      if (b + 8 < nch) s0 += t1;
+      if (b + 16 < nch) s0 += t2;
+      if (b + 24 < nch) s0 += t3;
+      s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64); s0 += __shfl_xor(s0, 4, 64);
+      return s0;
+    };
+    float mu[A];
+#pragma unroll
+    for (int o = 0; o < A; ++o) mu[o] = comb(p[o], nca) + h.d_ba[o];
+    const float val = comb(pv, ncc) + h.d_bc[0];
+    float lp = 0.0f;
+    if (lane < 8) {
+#pragma unroll 1
+      for (int kk = 0; kk < (A + 7) / 8; ++kk) {
+        const int k = lane + 8 * kk;
+        if (k < A) {
+          float z;
+          if (h.d_inject_normal) z = h.d_inject_normal[(size_t)env * A + k];
+          else {
+            uint32_t r[4];
+            pf_philox_raw(h.env_base + (uint32_t)env, h.counter, 1u, (uint32_t)k, h.seed_lo, h.seed_hi, r);
+            const float u1 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+            const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+            z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+          }
+          float m = 0.0f;
+#pragma unroll
+          for (int o = 0; o < A; ++o) if (o == k) m = mu[o];
+          const float sg = h.d_std[k];
+          const float a = m + sg * z;
+          const float d = (a - m) / sg;
+          lp += -0.5f * d * d - logf(sg) - 0.91893853320467274178f;
+          h.d_actions_out[(size_t)env * A + k] = a;
+          h.s_actions[(size_t)env * A + k] = a; h.s_mu[(size_t)env * A + k] = m; h.s_sigma[(size_t)env * A + k] = sg;
+          S[LC::actions + k] = pf_clip(a, -c.clip_actions, c.clip_actions);   // :176-177
+        }
+      }
+    }
+    lp += __shfl_xor(lp, 1, 64); lp += __shfl_xor(lp, 2, 64); lp += __shfl_xor(lp, 4, 64);
+    if (lane == 0) {
+      h.s_values[env] = val; h.s_log_prob[env] = lp;
+      if (proc) {      // PPO.process_env_step + the runner's episode bookkeeping (pf_ppo.hip process_store)
+        float r = pr;
+        if (h.p_ep_ret) {
+          float cr = per + r, cl = pel + 1.0f;
+          if (pdone) {
+            if (h.p_fin_ret) { h.p_fin_ret[env] = cr; h.p_fin_len[env] = cl; }
+            else { atomicAdd(h.p_ep_stats, cr); atomicAdd(h.p_ep_stats + 1, cl); atomicAdd(h.p_ep_stats + 2, 1.0f); }
+            cr = 0.0f; cl = 0.0f;
+          }
+          h.p_ep_ret[env] = cr; h.p_ep_len[env] = cl;
+        }
+        if (h.p_time_outs) r += h.p_gamma * (pval * (pto ? 1.0f : 0.0f));
+        h.p_s_rew[env] = r; h.p_s_done[env] = pdone ? 1.0f : 0.0f;
+      }
+    }
+  }
+#endif
+
   // role (DUAL instances): 0 = the wavefront that runs the step (alone: every other instance), 1 = its partner, which runs the
   // contact side of every substep and nothing else
   // shv / slot (DUAL): the workgroup's array of per-robot blocks and this robot's index in it -- see the substep loop
@@ -1767,6 +1879,10 @@ struct PfKernel {
       if (g.mode == 2) observations(sh, c, L, B, inj, env, g.step_counter);      // mode 3: a read of the measured_heights attribute, nothing else is written
       return;
     }
+#if !defined(PF_HOST_EMU) && !defined(PF_NO_POLICY_HEADS)      // (-DPF_NO_POLICY_HEADS: A/B builds of the launch without the branch, tools/build_variant.sh)
+    if (g.heads.d_ha) policy_heads(sh, c, g.heads, env);      // pf_step_policy: the action comes from the policy's heads, computed here
+    else
+#endif
     PF_LANES(k, c.num_actions) S[LC::actions + k] = pf_clip(g.actions[(size_t)env * c.num_actions + k], -c.clip_actions, c.clip_actions);   // :176-177
     PF_SYNC();
     if (inj.d_root) {

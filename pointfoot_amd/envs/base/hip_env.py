@@ -192,6 +192,16 @@ class HipEnv:
         self._fill_extras()
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
+    def step_policy(self, heads):
+        """step() for a policy whose dense layers have run (PPO.act_hidden): the heads, the sampling and the transition store happen
+        inside the same launch, before the action is read (pf_step_policy).  Same outputs as step(alg.act(...)), bit for bit."""
+        self.common_step_counter += 1
+        self._next_stats_slot()
+        _abi.check(self._lib.pf_step_policy(self._h, C.byref(heads), self.common_step_counter, self._stream()), self._lib)
+        self._maybe_update_command_curriculum()
+        self._fill_extras()
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
     def step_injected(self, actions, inject):
         """parity-test entry: same launch with an injected PfInject (sim snapshot and/or random numbers)."""
         a = actions.detach().to(device=self.device, dtype=torch.float32).contiguous()

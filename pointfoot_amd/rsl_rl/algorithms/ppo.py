@@ -147,6 +147,24 @@ class PPO:
         self.transition.actions = self._actions
         return self._actions
 
+    def act_hidden(self, obs, critic_obs):
+        """PPO.act up to the last hidden layer, for an env that finishes the step itself (HipEnv.step_policy): returns the filled
+        PfPolicyHeads -- heads, sampling, transition store and a pending deferred process_env_step then run inside the env-step launch --
+        or None when this handle cannot hand its heads over (the caller falls back to act() + env.step())."""
+        t = self.storage.next_slot()
+        obs = obs.contiguous()
+        critic_obs = critic_obs.contiguous()
+        heads = _abi.PfPolicyHeads()
+        rc = self._lib.ppo_act_hidden(self._h, t, obs.data_ptr(), critic_obs.data_ptr(), self._actions.data_ptr(), self._sample_counter + 1,
+                                      _ptr(self.inject_normal), C.byref(heads), self._stream())
+        if rc == 2:
+            return None
+        _abi.check(rc, self._lib)
+        self._sample_counter += 1
+        self._hidden_obs = (obs, critic_obs)      # the step launch reads them: keep them alive until it has been enqueued
+        self.transition.actions = self._actions
+        return heads
+
     def process_env_step(self, rewards, dones, infos):
         t = self.storage.next_slot()
         to = infos.get('time_outs', None) if isinstance(infos, dict) else None

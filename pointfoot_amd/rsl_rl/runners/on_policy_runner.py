@@ -65,9 +65,17 @@ class OnPolicyRunner:
         """num_steps_per_env env steps + GAE; no host synchronisation inside."""
         alg, env = self.alg, self.env
         ep_infos = []
+        # The policy's heads, the sampling, the transition store and the deferred process_env_step ride in the env-step launch
+        # (PPO.act_hidden + HipEnv.step_policy: one launch fewer per policy step, same bits -- tests/test_gpu_train.py); needs an env with
+        # step_policy whose outputs persist.  PF_FUSED_POLICY_STEP=0: the two-call form  actions = alg.act(...); env.step(actions).
+        fused = os.environ.get("PF_FUSED_POLICY_STEP", "1") == "1" and hasattr(env, "step_policy") and getattr(alg, "env_outputs_persist", False)
         for _ in range(self.num_steps_per_env):
-            actions = alg.act(obs, critic_obs)
-            obs, privileged_obs, rewards, dones, infos = env.step(actions)
+            heads = alg.act_hidden(obs, critic_obs) if fused else None
+            if heads is not None:
+                obs, privileged_obs, rewards, dones, infos = env.step_policy(heads)
+            else:
+                actions = alg.act(obs, critic_obs)
+                obs, privileged_obs, rewards, dones, infos = env.step(actions)
             critic_obs = privileged_obs if privileged_obs is not None else obs
             alg.process_env_step(rewards, dones, infos)
             if (self.log_dir is not None or dp.collectives_on()) and 'episode' in infos:

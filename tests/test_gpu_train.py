@@ -320,3 +320,53 @@ def test_measure_heights_actor_env_and_training_iteration():
             task_registry.make_env("pointfoot_rough", args=_args("pointfoot_rough", n), env_cfg=env_cfg)
     finally:
         env_cfg.terrain.measure_heights_actor, env_cfg.env.num_propriceptive_obs = saved
+
+
+@pytest.mark.parametrize("task,n", [("pointfoot_rough", 96), ("pointfoot_flat", 33), ("anymal_c_rough", 40)])
+def test_policy_heads_inside_the_step_launch_give_the_same_bits(task, n, monkeypatch):
+    """pf_step_policy (PF_FUSED_POLICY_STEP=1): the policy's heads, the sampling, the transition store and the deferred
+    process_env_step run inside the env-step launch instead of k_act_heads (rsl_rl OnPolicyRunner.learn: actions = alg.act(...);
+    env.step(actions); alg.process_env_step(...), call site legged_gym/scripts/train.py:44).  Same sums in the same order, same Philox
+    keys: two rollouts + one update from the same seeds must leave the SAME BITS in the storage, the env and the parameters."""
+    from pointfoot_amd.envs import task_registry
+
+    first = {}
+
+    def run(fused):
+        monkeypatch.setenv("PF_FUSED_POLICY_STEP", "1" if fused else "0")
+        args = _args(task, n)
+        env, _ = task_registry.make_env(task, args=args)
+        runner, _ = task_registry.make_alg_runner(env, task, args=args, log_root=None)
+        if "params" in first:      # the same initial policy for both runs (torch's initialisers do not restart with the env's seed)
+            runner.alg.params.copy_(first["params"])
+        else:
+            first["params"] = runner.alg.params.clone()
+        obs = env.get_observations()
+        cobs = env.get_privileged_observations()
+        cobs = cobs if cobs is not None else obs
+        calls = {"policy": 0}
+        orig = env.step_policy
+
+        def counted(h):
+            calls["policy"] += 1
+            return orig(h)
+        env.step_policy = counted
+        out = {}
+        for it in range(2):
+            obs, cobs, _ = runner.rollout(obs, cobs)
+            st = runner.alg.storage
+            for k in ("observations", "privileged_observations", "actions", "values", "actions_log_prob", "mu", "sigma", "rewards", "dones", "returns"):
+                out[f"{k}{it}"] = getattr(st, k).clone()
+            out[f"ep{it}"] = runner._ep_stats.clone()
+            if it == 0:
+                torch.manual_seed(5)
+                runner.alg.update()
+        torch.cuda.synchronize()
+        out["params"] = runner.alg.params.clone()
+        out["obs"], out["rew"], out["reset"] = env.obs_buf.clone(), env.rew_buf.clone(), env.reset_buf.clone()
+        assert calls["policy"] == (2 * runner.num_steps_per_env if fused else 0)
+        return out
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k} differs between the two-launch and the fused policy step"
