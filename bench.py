@@ -114,17 +114,18 @@ PPO_MFLOP_PER_ENV_STEP = 13.4  # 0.84 rollout + 12.5 update
 # writes it from separate --pmc passes: the L2's memory-side read / write requests by size -- the exact form of the guide's gfx950
 # doubling rule, profiles/r4_fetch_size_gather_calibration.txt); used only when kernel, task and env count match.
 TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", f) for f in
-                    ("r4_step_kernel_hbm_pmc.json", "r4_step_kernel_hbm_pmc_anymal_c_rough.json")]      # profiles of the kernels as they are NOW
+                    ("r4_step_kernel_hbm_pmc_policy_step.json",      # the launch WITH the policy's tail (pf_step_policy: "policy_tail": true)
+                     "r4_step_kernel_hbm_pmc.json", "r4_step_kernel_hbm_pmc_anymal_c_rough.json")]      # profiles of the kernels as they are NOW
 # (older summaries -- r3_step_kernel_hbm_pmc*.json, r2_... -- describe kernels that no longer exist: single-wavefront PointFoot instance,
 # whole-record loads; they are not offered as this build's traffic)
 
 
-def step_traffic(kernel_prefix, task, num_envs):
-    for path in TRAFFIC_PROFILES:      # newest first; a file is used only for the kernel instance, task and env count it was measured on
+def step_traffic(kernel_prefix, task, num_envs, tail=False):
+    for path in TRAFFIC_PROFILES:      # a file is used only for the kernel instance, task, env count and kind of launch (with / without the policy's tail) it was measured on
         try:
             with open(path) as f:
                 p = json.load(f)
-            if kernel_prefix in p["kernel"].replace(" ", "") and p["task"] == task and int(p["num_envs"]) == num_envs:
+            if kernel_prefix in p["kernel"].replace(" ", "") and p["task"] == task and int(p["num_envs"]) == num_envs and bool(p.get("policy_tail", False)) == bool(tail):
                 return float(p["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
@@ -551,7 +552,7 @@ def main():
         x6 = env_gemm == "2" or (env_gemm is None and widest >= 256)
         gemm_name = ("pf_gemm3_* (fp32 by exact three-way bf16 operand split on v_mfma_f32_32x32x16_bf16, fp32 accumulation)" if x6
                      else "pf_gemm_* (v_mfma_f32_32x32x2_f32)")
-        traffic, traffic_src = step_traffic("pf_step_kernel<17" if anymal else "pf_step_kernel<9", a.task, a.num_envs)
+        traffic, traffic_src = step_traffic("pf_step_kernel<17" if anymal else "pf_step_kernel<9", a.task, a.num_envs, tail=fused_step)
         out = {
             "metric": "env-steps/sec (whole node), pointfoot_rough 4096 envs/GPU" if headline else f"env-steps/sec (whole node), {a.task} {a.num_envs} envs/GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
@@ -581,8 +582,8 @@ def main():
                                           "achieved_with_tail": (bytes_per_env + tail_bytes) * a.num_envs / (step_ms * 1e-3) / 1e9,
                                           "note": "the launch also carries the policy's heads, the sampling and RolloutStorage.add_transitions (pf_step_policy: "
                                                   "last hidden rows read, observation rows copied, action / mean / sigma / value / log-prob stored), which used to be "
-                                                  "a launch of their own (k_act_heads, 12 us); `achieved` / `frac` count the env step's SURVEY 8d bytes only, and "
-                                                  "`traffic` was measured on the launch without the tail (pf_step)"} if fused_step else {"in_this_launch": False}),
+                                                  "a launch of their own (k_act_heads, 12 us); `achieved` / `frac` count the env step's SURVEY 8d bytes only, while "
+                                                  "`traffic` (PMC) is that of the whole launch, tail included: compare it with bytes_per_launch + policy_tail.bytes_per_launch"} if fused_step else {"in_this_launch": False}),
                          "note": "VALU-issue- and latency-bound, not HBM-bound (SURVEY §8d honesty note; DESIGN §4.1); launch_ms from HIP events around every 8th launch, on the launch stream"},
             "roofline_ppo": {"kernel": gemm_name + " inside the PPO update", "bound": "mfma", "achieved": ach_tf,
                              "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / MFMA_F32_PEAK_TFLOPS,

@@ -15,8 +15,8 @@
 
 // The quadruped instances are compiled in a translation unit of their own (pf_env_quad.hip: they want the iterative-ilp scheduler,
 // the PointFoot instance -- 128 VGPRs -- the default one: no register spills, no scratch traffic).
-extern template __global__ void pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, PF_KPAIR_QUAD, PF_NBD_QUAD, false>(const void* __restrict__, const PfConfig* __restrict__, PfStepArgs);
-extern template __global__ void pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, 0, PF_NBD_QUAD, false>(const void* __restrict__, const PfConfig* __restrict__, PfStepArgs);
+extern template __global__ void pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, PF_KPAIR_QUAD, PF_NBD_QUAD, false>(const void* __restrict__, const PfConfig* __restrict__, PfStepArgs, const PfPolicyHeads);
+extern template __global__ void pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, 0, PF_NBD_QUAD, false>(const void* __restrict__, const PfConfig* __restrict__, PfStepArgs, const PfPolicyHeads);
 
 thread_local std::string g_pf_error;
 void pf_set_error(const std::string& s) { g_pf_error = s; }
@@ -245,7 +245,8 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
     pf_set_error("pf_step: incomplete injected sim state"); return 1;
   }
   g.actions = d_actions; g.step_counter = step_counter; g.mode = mode; g.stamps = e->d_stamps; g.reset_mask = d_mask;
-  if (heads) g.heads = *heads; else std::memset(&g.heads, 0, sizeof(g.heads));
+  PfPolicyHeads hd;      // a kernel argument of its own (pf_step_entry.h); all zero: plain pf_step
+  if (heads) hd = *heads; else std::memset(&hd, 0, sizeof(hd));
   hipStream_t s = (hipStream_t)stream;
   g.stats_next = nullptr;
   if (e->bufs.d_reset_stats && mode < 2) {
@@ -262,7 +263,7 @@ static int pf_launch(PfEnv* e, const float* d_actions, int64_t step_counter, con
   auto launch = [&](auto kern, size_t lds, int robots_per_block, int threads) {
     static bool raised = false;          // one kernel per env handle in practice; raising the limit again is harmless
     if (lds > 64 * 1024 && !raised) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
-    hipLaunchKernelGGL(kern, dim3((N + robots_per_block - 1) / robots_per_block), dim3(threads), lds, s, e->d_packed, e->d_cfg, g);
+    hipLaunchKernelGGL(kern, dim3((N + robots_per_block - 1) / robots_per_block), dim3(threads), lds, s, e->d_packed, e->d_cfg, g, hd);
   };
   if (e->instance == 2) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, PF_KPAIR_QUAD, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuadSelf, 1, PF_QUAD_WPB>(), PF_QUAD_WPB, 64 * PF_QUAD_WPB);
   else if (e->instance == 1) launch(pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, 0, PF_NBD_QUAD>, pf_lds_bytes<PfKernelQuad, 1, PF_QUAD_WPB>(), PF_QUAD_WPB, 64 * PF_QUAD_WPB);

@@ -4,5 +4,5 @@
 // instance of pf_env.hip is compiled with the default scheduler (zero register spills at its 128 VGPRs).
 #include "pf_step_entry.h"
 
-template __global__ void pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, PF_KPAIR_QUAD, PF_NBD_QUAD, false>(const void* __restrict__, const PfConfig* __restrict__, PfStepArgs);
-template __global__ void pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, 0, PF_NBD_QUAD, false>(const void* __restrict__, const PfConfig* __restrict__, PfStepArgs);
+template __global__ void pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, PF_KPAIR_QUAD, PF_NBD_QUAD, false>(const void* __restrict__, const PfConfig* __restrict__, PfStepArgs, const PfPolicyHeads);
+template __global__ void pf_step_kernel<17, 12, 4, 2, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD, 1, PF_QUAD_WPB, 0, PF_NBD_QUAD, false>(const void* __restrict__, const PfConfig* __restrict__, PfStepArgs, const PfPolicyHeads);

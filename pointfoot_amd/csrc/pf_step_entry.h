@@ -36,7 +36,7 @@ using PfKernelQuadSelf = PfKernel<17, 12, 4, PF_KIND_LEGGED_ROBOT, PF_KSPH_QUAD,
 // DUAL: a workgroup is TWO wavefronts for the same RPW robots (WPB == 1): wave 0 runs the step, wave 1 the contact side of its
 // substeps (PfKernel::run, role).
 template <int NB, int ND, int NF, int WAVES, int KIND = PF_KIND_POINTFOOT, int KS = PF_KSPH, int RPW = 1, int WPB = 1, int KPR = (KIND == PF_KIND_POINTFOOT ? 16 : 0), int NBD = NB, bool DUAL = false>
-__global__ __launch_bounds__(64 * WPB * (DUAL ? 2 : 1), (WPB == 1 || DUAL) ? WAVES : (WPB <= 4 ? 2 : 1)) void pf_step_kernel(const void* __restrict__ packed, const PfConfig* __restrict__ cfg, PfStepArgs g) {
+__global__ __launch_bounds__(64 * WPB * (DUAL ? 2 : 1), (WPB == 1 || DUAL) ? WAVES : (WPB <= 4 ? 2 : 1)) void pf_step_kernel(const void* __restrict__ packed, const PfConfig* __restrict__ cfg, PfStepArgs g, const PfPolicyHeads heads) {
   using K = PfKernel<NB, ND, NF, KIND, KS, RPW, KPR, NBD, DUAL>;
   static_assert(!DUAL || WPB == 1, "a DUAL workgroup is one pair of wavefronts");
   extern __shared__ __attribute__((aligned(16))) unsigned char pf_lds[];
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * WPB * (DUAL ? 2 : 1), (WPB == 1 || DUAL) ? WAV
   const int slot = tid / (64 / RPW);                         // robot slot inside the workgroup
   const int env = (int)blockIdx.x * (RPW * WPB) + slot;
   if (env >= cfg->num_envs) return;
-  K::run(sh[slot], ro, g, env, DUAL ? ((int)threadIdx.x >> 6) : 0, sh, slot);
+  K::run(sh[slot], ro, g, env, DUAL ? ((int)threadIdx.x >> 6) : 0, sh, slot, &heads);
 }
 template <class K, int RPW, int WPB>
 static constexpr size_t pf_lds_bytes() {

@@ -221,7 +221,6 @@ struct PfStepArgs {
   unsigned* stamps;       // diagnostic build only, else NULL
   float* stats_next;      // next step's statistics slot, cleared by this launch (NULL: the host clears slots itself)
   const uint8_t* reset_mask;   // mode 1 only: envs to reset (NULL: all) -- reset_idx(env_ids), point_foot.py:249
-  PfPolicyHeads heads;         // pf_step_policy: the policy's heads, sampling and transition store run here (d_ha == NULL: plain pf_step)
 };
 
 // KPR: self-collision capsule pairs the instance is built for (0: built without self-collision)
@@ -1817,7 +1816,9 @@ struct PfKernel {
   // role (DUAL instances): 0 = the wavefront that runs the step (alone: every other instance), 1 = its partner, which runs the
   // contact side of every substep and nothing else
   // shv / slot (DUAL): the workgroup's array of per-robot blocks and this robot's index in it -- see the substep loop
-  PF_DEV void run(Shared& sh, SharedRO& ro, const PfStepArgs& g, int env, int role = 0, Shared* shv = nullptr, int slot = 0) {
+  // hp (pf_step_policy): the policy's tail -- a kernel argument of its own, never written, so that it stays in the kernel-argument segment and is
+  // scalar-loaded where the prologue uses it (inside PfStepArgs, which the entry point modifies, its 272 bytes were loaded up front: 113 spilled SGPRs)
+  PF_DEV void run(Shared& sh, SharedRO& ro, const PfStepArgs& g, int env, int role = 0, Shared* shv = nullptr, int slot = 0, const PfPolicyHeads* hp = nullptr) {
     const PfConfig& c = *g.cfg; const PfLayout& L = g.L; const PfBuffers& B = g.b; const PfInject& inj = g.inj;
     ModelS& ms = ro.mdl;
     if constexpr (DUAL) { if (role == 1 && (g.mode != 0 || inj.d_root)) return; }      // no substeps: nothing for the partner to do
@@ -1880,7 +1881,7 @@ struct PfKernel {
       return;
     }
 #if !defined(PF_HOST_EMU) && !defined(PF_NO_POLICY_HEADS)      // (-DPF_NO_POLICY_HEADS: A/B builds of the launch without the branch, tools/build_variant.sh)
-    if (g.heads.d_ha) policy_heads(sh, c, g.heads, env);      // pf_step_policy: the action comes from the policy's heads, computed here
+    if (hp && hp->d_ha) policy_heads(sh, c, *hp, env);      // pf_step_policy: the action comes from the policy's heads, computed here
     else
 #endif
     PF_LANES(k, c.num_actions) S[LC::actions + k] = pf_clip(g.actions[(size_t)env * c.num_actions + k], -c.clip_actions, c.clip_actions);   // :176-177
