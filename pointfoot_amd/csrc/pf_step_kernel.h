@@ -1748,9 +1748,18 @@ struct PfKernel {
       if (h.p_time_outs) { pto = h.p_time_outs[env] != 0; pval = h.p_values[env]; }
     }
     // RolloutStorage.add_transitions: the observations the policy acted on (this env's rows)
+    // (eight loads in flight per lane, then the stores: the compiler cannot prove that the storage rows do not alias the observation
+    // buffers, so a load-store loop would be one memory round trip per iteration)
     { const int O = h.num_obs, P = h.num_critic_obs;
-      PF_LANES(i, O) h.s_obs[(size_t)env * O + i] = h.d_obs[(size_t)env * O + i];
-      PF_LANES(i, P) h.s_critic_obs[(size_t)env * P + i] = h.d_critic_obs[(size_t)env * P + i]; }
+      const float* so = h.d_obs + (size_t)env * O; const float* sc = h.d_critic_obs + (size_t)env * P;
+      float* to = h.s_obs + (size_t)env * O; float* tc = h.s_critic_obs + (size_t)env * P;
+      for (int i0 = 0; i0 < O + P; i0 += 8 * PF_W) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * PF_W + lane; t[u] = i < O ? so[i] : (i < O + P ? sc[i - O] : 0.0f); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * PF_W + lane; if (i < O) to[i] = t[u]; else if (i < O + P) tc[i - O] = t[u]; }
+      } }
     auto comb = [&](float q, int nch) {
       float s0 = __shfl(q, hb + b, 64);
       const float t1 = __shfl(q, hb + b + 8, 64), t2 = __shfl(q, hb + b + 16, 64), t3 = __shfl(q, hb + b + 24, 64);
